@@ -1,0 +1,95 @@
+"""ctypes binding of libdktstereo.so (include/dktstereo.h).
+
+This is the whole Python<->native boundary of the package: device pointers come
+from ``tensor.data_ptr()``, the stream from ``torch.cuda.current_stream()``; no
+torch type crosses the ABI.  There is no CPU fallback -- if the library is
+missing or a call fails this module raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdktstereo.so")
+
+_c_f32p = ctypes.c_void_p
+_i, _l, _f, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> argtypes, mirrors include/dktstereo.h one to one
+SIGNATURES = {
+    "dkt_corr1d_build": [_vp, _vp, _pp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "dkt_corr1d_lookup": [_pp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_corr1d_lookup_otf": [_vp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_pool_w": [_vp, _vp, _l, _i, _i, _vp],
+    "dkt_l2norm_channels": [_vp, _vp, _i, _i, _l, _i, _vp],
+    "dkt_pool_d": [_vp, _vp, _l, _i, _l, _i, _vp],
+    "dkt_geo_lookup": [_pp, _pp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_gwc_volume": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _i, _vp],
+    "dkt_concat_volume": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _i, _vp],
+    "dkt_gru_gate_zr": [_vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _i, _l, _i, _vp],
+    "dkt_gru_gate_out": [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _i, _i, _l, _i, _vp],
+}
+
+_lib = None
+
+
+class DktError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DktError(
+                "libdktstereo.so is missing (%s). Build it with "
+                "`python -m dkt_stereo_amd.build` (needs hipcc); there is no fallback path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.dkt_version.restype = ctypes.c_int
+        L.dkt_version.argtypes = []
+        L.dkt_strerror.restype = ctypes.c_char_p
+        L.dkt_strerror.argtypes = [ctypes.c_int]
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DktError("%s failed: %s (rc=%d)" % (what, lib().dkt_strerror(rc).decode(), rc))
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return ctypes.cast(arr, _pp)
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def device_of(t):
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise DktError("dkt_stereo_amd operators run on a HIP device only (got a %s tensor); "
+                           "there is no CPU path in the product" % t.device)
+        if t.dtype != torch.float32:
+            raise DktError("dkt_stereo_amd operators are float32 (got %s)" % t.dtype)
+
+
+def require_no_grad(*tensors):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        raise DktError("the HIP path is inference-only: call under torch.no_grad() "
+                       "(autograd through these operators is not implemented)")

@@ -1,0 +1,182 @@
+"""Drop-in replacements for the correlation classes of the reference's
+``core/corr.py`` (identical copy: ``meta_arch/raft_stereo/corr.py``), backed by
+the HIP kernels of libdktstereo.so through ``_ffi``.
+
+Same constructor / call signatures and attributes as the reference, so
+``RAFTStereo.forward`` (meta_arch/raft_stereo/raft_stereo.py:118-154) can use
+them unchanged:
+
+    corr_fn = CorrBlock1D(fmap1, fmap2, radius=4, num_levels=4)
+    corr = corr_fn(coords1)            # (B, L*(2r+1), H, W) float32 contiguous
+
+Inference only (the reference's training path needs autograd through
+grid_sample; that is a later row of SURVEY.md section 8f).
+"""
+import torch
+
+from . import _ffi
+
+
+def _build_pyramid(fmap1, fmap2, num_levels, divisor):
+    """dkt_corr1d_build: all-pairs correlation + avg-pool pyramid in one launch.
+    Returns L tensors shaped like the reference's pyramid entries (N,1,1,W2_i)."""
+    _ffi.require_gpu(fmap1, fmap2)
+    _ffi.require_no_grad(fmap1, fmap2)
+    fmap1 = fmap1.contiguous()
+    fmap2 = fmap2.contiguous()
+    B, C, H, W1 = fmap1.shape
+    B2, C2, H2, W2 = fmap2.shape
+    if (B, C, H) != (B2, C2, H2):
+        raise ValueError("fmap1 %s and fmap2 %s disagree" % (tuple(fmap1.shape), tuple(fmap2.shape)))
+    N = B * H * W1
+    pyr = [torch.empty((N, 1, 1, W2 >> i), device=fmap1.device, dtype=torch.float32)
+           for i in range(num_levels)]
+    rc = _ffi.lib().dkt_corr1d_build(fmap1.data_ptr(), fmap2.data_ptr(), _ffi.ptr_array(pyr),
+                                     B, C, H, W1, W2, num_levels, float(divisor),
+                                     _ffi.device_of(fmap1), _ffi.stream_of(fmap1))
+    _ffi.check(rc, "dkt_corr1d_build")
+    return pyr
+
+
+def _lookup(pyramid, coords, radius, w2):
+    _ffi.require_gpu(coords)
+    B, _, H, W1 = coords.shape
+    if coords.stride(3) != 1 or coords.stride(2) != W1:
+        coords = coords.contiguous()
+    L = len(pyramid)
+    K = 2 * radius + 1
+    out = torch.empty((B, L * K, H, W1), device=coords.device, dtype=torch.float32)
+    # only channel 0 (x) is read, like coords[:, :1] in core/corr.py:129
+    rc = _ffi.lib().dkt_corr1d_lookup(_ffi.ptr_array(pyramid), coords.data_ptr(), coords.stride(0),
+                                      out.data_ptr(), B, H, W1, w2, L, radius,
+                                      _ffi.device_of(coords), _ffi.stream_of(coords))
+    _ffi.check(rc, "dkt_corr1d_lookup")
+    return out
+
+
+class CorrBlock1D:
+    """core/corr.py:110-156.  ``corr_pyramid`` holds the ``num_levels`` levels that
+    ``__call__`` reads (the reference also stores one more pooled level that
+    nothing ever reads)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        C = fmap1.shape[1]
+        # corr / sqrt(C) (core/corr.py:156); the kernel divides like the reference
+        self._w2 = fmap2.shape[3]
+        self.corr_pyramid = _build_pyramid(fmap1.float(), fmap2.float(), num_levels,
+                                           float(torch.sqrt(torch.tensor(C).float())))
+
+    def __call__(self, coords):
+        return _lookup(self.corr_pyramid, coords, self.radius, self._w2)
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        B, D, H, W1 = fmap1.shape
+        W2 = fmap2.shape[3]
+        lvl0, = _build_pyramid(fmap1.float(), fmap2.float(), 1,
+                               float(torch.sqrt(torch.tensor(D).float())))
+        return lvl0.view(B, H, W1, 1, W2)
+
+
+class CorrBlockFast1D(CorrBlock1D):
+    """core/corr.py:31-61 ("reg_cuda").  The reference needs the un-vendored
+    ``corr_sampler`` CUDA extension for this class; here it is the same HIP
+    lookup as CorrBlock1D, with the reference's 5-D pyramid views."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        super().__init__(fmap1, fmap2, num_levels=num_levels, radius=radius)
+        B, _, H, W1 = fmap1.shape
+        self._flat = self.corr_pyramid
+        self.corr_pyramid = [p.view(B, H, W1, -1, p.shape[-1]) for p in self._flat]
+
+    def __call__(self, coords):
+        return _lookup(self._flat, coords, self.radius, self._w2)
+
+
+class CorrBlock1D_Cosine(CorrBlock1D):
+    """core/corr.py:160-209: L2-normalised features, no 1/sqrt(C) scaling.
+    (The ``mix=`` training-time blend of meta_arch/raft_stereo/corr.py:216-228 is
+    not part of the inference path.)"""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        self._w2 = fmap2.shape[3]
+        self.corr_pyramid = _build_pyramid(self._normalise(fmap1), self._normalise(fmap2), num_levels, 1.0)
+
+    @staticmethod
+    def _normalise(fmap):
+        fmap = fmap.float().contiguous()
+        _ffi.require_gpu(fmap)
+        B, C, H, W = fmap.shape
+        out = torch.empty_like(fmap)
+        rc = _ffi.lib().dkt_l2norm_channels(fmap.data_ptr(), out.data_ptr(), B, C, H * W,
+                                            _ffi.device_of(fmap), _ffi.stream_of(fmap))
+        _ffi.check(rc, "dkt_l2norm_channels")
+        return out
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        B, D, H, W1 = fmap1.shape
+        W2 = fmap2.shape[3]
+        lvl0, = _build_pyramid(CorrBlock1D_Cosine._normalise(fmap1),
+                               CorrBlock1D_Cosine._normalise(fmap2), 1, 1.0)
+        return lvl0.view(B, H, W1, 1, W2)
+
+
+class PytorchAlternateCorrBlock1D:
+    """core/corr.py:64-107 ("alt"): no correlation volume, O(H*W*C) memory; every
+    call recomputes the 2r+1 correlations per level from the feature maps."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.corr_pyramid = []
+        _ffi.require_gpu(fmap1, fmap2)
+        _ffi.require_no_grad(fmap1, fmap2)
+        self.fmap1 = fmap1.float().contiguous()
+        self.fmap2 = fmap2.float().contiguous()
+        # right feature map pooled along W once per level (corr.py:104 does it per call)
+        self._f2pyr = [self.fmap2]
+        B, C, H, W2 = self.fmap2.shape
+        for i in range(1, num_levels):
+            src = self._f2pyr[-1]
+            dst = torch.empty((B, C, H, src.shape[3] // 2), device=src.device, dtype=torch.float32)
+            rc = _ffi.lib().dkt_pool_w(src.data_ptr(), dst.data_ptr(), B * C * H, src.shape[3],
+                                       _ffi.device_of(src), _ffi.stream_of(src))
+            _ffi.check(rc, "dkt_pool_w")
+            self._f2pyr.append(dst)
+
+    def __call__(self, coords):
+        _ffi.require_gpu(coords)
+        coords = coords.contiguous()
+        B, C, H, W1 = self.fmap1.shape
+        W2 = self.fmap2.shape[3]
+        K = 2 * self.radius + 1
+        out = torch.empty((B, self.num_levels * K, H, W1), device=coords.device, dtype=torch.float32)
+        rc = _ffi.lib().dkt_corr1d_lookup_otf(self.fmap1.data_ptr(), _ffi.ptr_array(self._f2pyr),
+                                              coords.data_ptr(), out.data_ptr(), B, C, H, W1, W2,
+                                              self.num_levels, self.radius,
+                                              _ffi.device_of(coords), _ffi.stream_of(coords))
+        _ffi.check(rc, "dkt_corr1d_lookup_otf")
+        return out
+
+
+class AlternateCorrBlock:
+    """core/corr.py:212-241: disabled upstream (raises before doing anything)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        raise NotImplementedError
+
+
+#: value of ``args.corr_implementation`` -> class, as selected in
+#: meta_arch/raft_stereo/raft_stereo.py:118-132
+CORR_IMPLEMENTATIONS = {
+    "reg": CorrBlock1D,
+    "alt": PytorchAlternateCorrBlock1D,
+    "reg_cuda": CorrBlockFast1D,
+    "alt_cuda": AlternateCorrBlock,
+    "cosine": CorrBlock1D_Cosine,
+}

@@ -1,0 +1,73 @@
+// dkt_common.h -- shared host/device helpers for libdktstereo (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dktstereo.h"
+
+#define DKT_WAVE 64
+
+// RAII-free device scope: switch to `device` (if >=0 and different) for the
+// duration of one ABI call, restore on exit.  No global state.
+struct DktDeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DktDeviceScope(int device) {
+        if (device < 0) return;
+        err = hipGetDevice(&prev);
+        if (err != hipSuccess) return;
+        if (prev != device) {
+            err = hipSetDevice(device);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DktDeviceScope() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+#define DKT_ENTER(device)                  \
+    DktDeviceScope _scope(device);         \
+    if (_scope.err != hipSuccess) return (int)_scope.err
+
+// consume (and return) any launch error without synchronising
+static inline int dkt_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DKT_OK : (int)e;
+}
+
+struct DktPtrs {
+    const float *p[DKT_MAX_LEVELS];
+};
+struct DktMutPtrs {
+    float *p[DKT_MAX_LEVELS];
+};
+
+// ---------------------------------------------------------------------------
+// The reference's sampler arithmetic, bit for bit
+// (core/utils/utils.py:63 + ATen grid_sample, align_corners=True, zero pad):
+//   xg = 2*x/(W-1) - 1 ;  ix = (xg + 1) * ((W-1)/2)
+//   fl = floor(ix) ; w = ix - fl ; e = 1 - w
+//   out = fma(v[fl+1], w, v[fl]*e)
+// Explicit _rn intrinsics so that -ffp-contract cannot fuse anything else.
+// ---------------------------------------------------------------------------
+struct DktTap {
+    float fl;  // floor(ix) as float
+    float w;   // weight of tap fl+1
+    float e;   // weight of tap fl
+};
+
+__device__ __forceinline__ DktTap dkt_tap(float x, float wm1, float half_wm1) {
+    float xg = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, x), wm1), 1.0f);
+    float ix = __fmul_rn(__fadd_rn(xg, 1.0f), half_wm1);
+    DktTap t;
+    t.fl = floorf(ix);
+    t.w = __fsub_rn(ix, t.fl);
+    t.e = __fsub_rn(1.0f, t.w);
+    return t;
+}
+
+__device__ __forceinline__ float dkt_blend(float v0, float v1, const DktTap &t) {
+    return __fmaf_rn(v1, t.w, __fmul_rn(v0, t.e));
+}

@@ -1,0 +1,153 @@
+// geo.hip -- IGEV Combined_Geo_Encoding_Volume lookup for gfx950.
+// Reference: meta_arch/igev_stereo/geometry.py:6-58.
+//
+// The reference first permutes the (B,C,D,H,W) geometry volume to (N,C,1,D)
+// (an 88 MB copy at 184x312, geometry.py:18) so that grid_sample can treat D as
+// the width axis.  Here the volume is read in its native layout: for a fixed
+// (c,d) plane neighbouring pixels are neighbouring floats, so with lanes along
+// w a tap load is a (near-)contiguous wave read whenever disparity is locally
+// smooth, and no copy is made.
+#include "dkt_common.h"
+
+struct GeoArgs {
+    DktPtrs geo;   // level i: (B,C,D>>i,H,W)
+    DktPtrs init;  // level i: (B*H*W, W2>>i)
+    const float *disp;
+    const float *coords;
+    float *out;
+    long HW;
+    int C, D, W2, L;
+};
+
+__device__ __forceinline__ int geo_clamp_idx(float fl, int W) {
+    return (int)fminf(fmaxf(fl, -2.0f), (float)W + 1.0f);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void geo_lookup_kernel(GeoArgs a) {
+    constexpr int K = 2 * R + 1;
+    const long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= a.HW) return;
+    const int lv = blockIdx.y / (a.C + 1);
+    const int c = blockIdx.y % (a.C + 1);
+    const int b = blockIdx.z;
+    const size_t n = (size_t)b * a.HW + p;
+    const float inv = (float)(1 << lv);
+    const float dl = __fdiv_rn(a.disp[n], inv);
+    const int per_level = K * (a.C + 1);
+    float *o = a.out + ((size_t)b * a.L * per_level + (size_t)lv * per_level + (size_t)c * K) * a.HW + p;
+
+    if (c < a.C) {
+        // geometry volume: taps along D, plane stride HW
+        const int di = a.D >> lv;
+        const float wm1 = (float)(di - 1), hwm1 = __fdiv_rn(wm1, 2.0f);
+        const float *base = a.geo.p[lv] + ((size_t)b * a.C + c) * (size_t)di * a.HW + p;
+        DktTap taps[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) taps[k] = dkt_tap(__fadd_rn((float)(k - R), dl), wm1, hwm1);
+        const int i0 = geo_clamp_idx(taps[0].fl, di);
+        float win[K + 1];
+#pragma unroll
+        for (int j = 0; j <= K; ++j) {
+            const int d = i0 + j;
+            win[j] = (d >= 0 && d < di) ? base[(size_t)d * a.HW] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int ik = geo_clamp_idx(taps[k].fl, di);
+            float v0 = win[k], v1 = win[k + 1];
+            if (ik != i0 + k) {
+                v0 = (ik >= 0 && ik < di) ? base[(size_t)ik * a.HW] : 0.0f;
+                v1 = (ik + 1 >= 0 && ik + 1 < di) ? base[(size_t)(ik + 1) * a.HW] : 0.0f;
+            }
+            o[(size_t)k * a.HW] = dkt_blend(v0, v1, taps[k]);
+        }
+    } else {
+        // init correlation row: x = (coords/2^i - disp/2^i) + dx   (geometry.py:50)
+        const int wi = a.W2 >> lv;
+        const float wm1 = (float)(wi - 1), hwm1 = __fdiv_rn(wm1, 2.0f);
+        const float *row = a.init.p[lv] + n * (size_t)wi;
+        const float cl = __fdiv_rn(a.coords[n], inv);
+        const float xc = __fsub_rn(cl, dl);
+        DktTap taps[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) taps[k] = dkt_tap(__fadd_rn(xc, (float)(k - R)), wm1, hwm1);
+        const int i0 = geo_clamp_idx(taps[0].fl, wi);
+        float win[K + 1];
+#pragma unroll
+        for (int j = 0; j <= K; ++j) {
+            const int x = i0 + j;
+            win[j] = (x >= 0 && x < wi) ? row[x] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int ik = geo_clamp_idx(taps[k].fl, wi);
+            float v0 = win[k], v1 = win[k + 1];
+            if (ik != i0 + k) {
+                v0 = (ik >= 0 && ik < wi) ? row[ik] : 0.0f;
+                v1 = (ik + 1 >= 0 && ik + 1 < wi) ? row[ik + 1] : 0.0f;
+            }
+            o[(size_t)k * a.HW] = dkt_blend(v0, v1, taps[k]);
+        }
+    }
+}
+
+template <int R>
+static void launch_geo(const GeoArgs &a, int B, hipStream_t st) {
+    dim3 grid((unsigned)((a.HW + 255) / 256), (unsigned)(a.L * (a.C + 1)), (unsigned)B);
+    hipLaunchKernelGGL(geo_lookup_kernel<R>, grid, dim3(256), 0, st, a);
+}
+
+extern "C" int dkt_geo_lookup(const float *const *geo_pyr, const float *const *init_pyr,
+                              const float *disp, const float *coords, float *out,
+                              int B, int C, int D, int H, int W, int W2, int L, int r,
+                              int device, void *stream) {
+    if (!geo_pyr || !init_pyr || !disp || !coords || !out) return DKT_E_NULL;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || W2 <= 0 || B > 65535) return DKT_E_SHAPE;
+    if (L < 1 || L > DKT_MAX_LEVELS || (W2 >> (L - 1)) == 0 || (D >> (L - 1)) == 0) return DKT_E_LEVELS;
+    if ((long)L * (C + 1) > 65535) return DKT_E_SHAPE;
+    if (r < 0 || r > DKT_MAX_RADIUS) return DKT_E_RADIUS;
+    GeoArgs a;
+    for (int i = 0; i < DKT_MAX_LEVELS; ++i) {
+        a.geo.p[i] = i < L ? geo_pyr[i] : nullptr;
+        a.init.p[i] = i < L ? init_pyr[i] : nullptr;
+        if (i < L && (!geo_pyr[i] || !init_pyr[i])) return DKT_E_NULL;
+    }
+    DKT_ENTER(device);
+    a.disp = disp; a.coords = coords; a.out = out;
+    a.HW = (long)H * W; a.C = C; a.D = D; a.W2 = W2; a.L = L;
+    hipStream_t st = (hipStream_t)stream;
+    switch (r) {
+        case 0: launch_geo<0>(a, B, st); break;
+        case 1: launch_geo<1>(a, B, st); break;
+        case 2: launch_geo<2>(a, B, st); break;
+        case 3: launch_geo<3>(a, B, st); break;
+        case 4: launch_geo<4>(a, B, st); break;
+        case 5: launch_geo<5>(a, B, st); break;
+        case 6: launch_geo<6>(a, B, st); break;
+        case 7: launch_geo<7>(a, B, st); break;
+        default: launch_geo<8>(a, B, st); break;
+    }
+    return dkt_launch_status();
+}
+
+// (B*C, D, HW) -> (B*C, D/2, HW), pairwise mean along D  (geometry.py:23-25)
+__global__ __launch_bounds__(256) void pool_d_kernel(const float *__restrict__ src,
+                                                     float *__restrict__ dst, int D, long HW) {
+    const int Do = D >> 1;
+    const long p = blockIdx.x * 256L + threadIdx.x;
+    if (p >= HW) return;
+    const long bc = blockIdx.y / Do;
+    const int d = blockIdx.y % Do;
+    const float *s = src + (bc * D + 2 * d) * HW + p;
+    dst[(bc * Do + d) * HW + p] = __fmul_rn(__fadd_rn(s[0], s[HW]), 0.5f);
+}
+
+extern "C" int dkt_pool_d(const float *src, float *dst, long BC, int D, long HW, int device, void *stream) {
+    if (!src || !dst) return DKT_E_NULL;
+    if (BC <= 0 || D < 2 || HW <= 0 || BC * (D >> 1) > 65535) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(BC * (D >> 1)));
+    hipLaunchKernelGGL(pool_d_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, D, HW);
+    return dkt_launch_status();
+}

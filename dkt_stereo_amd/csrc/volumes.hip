@@ -1,0 +1,114 @@
+// volumes.hip -- cost-volume builders for gfx950.
+//   dkt_gwc_volume     group-wise correlation volume
+//   dkt_concat_volume  shifted-copy concatenation volume (GwcNet / IGEV variants)
+// Reference: meta_arch/igev_stereo/submodule.py:152-170,207-218,
+//            meta_arch/gwcnet/submodules.py:25-58.
+// Both are HBM-write-bound (AI ~3 FLOP/B for gwc, 0 for concat): the kernels
+// are organised around full-width coalesced plane writes; the target row is
+// staged once in LDS so the D shifted re-reads never leave the CU.
+#include "dkt_common.h"
+
+// One block per (b, g, h) row.  LDS: tgt[cpg][W].  Each thread owns pixels
+// w = tid, tid+256, ... and for each d forms the group mean
+//   sum_j ref[j][w]*tgt[j][w-d] / cpg  (sequential fp32 sum of rounded products,
+// the order torch's mean over the strided group axis uses).
+#define GWC_MAX_CPG 16
+extern __shared__ __attribute__((aligned(16))) float gwc_lds[];
+
+__global__ __launch_bounds__(256) void gwc_volume_kernel(const float *__restrict__ ref,
+                                                         const float *__restrict__ tgt,
+                                                         float *__restrict__ vol, int C, int H, int W,
+                                                         int D, int G, long vol_bstride) {
+    const int cpg = C / G;
+    const int h = blockIdx.x % H;
+    const int g = (blockIdx.x / H) % G;
+    const int b = blockIdx.x / (H * G);
+    const size_t HW = (size_t)H * W;
+    const size_t chan0 = ((size_t)b * C + (size_t)g * cpg) * HW + (size_t)h * W;
+    for (int i = threadIdx.x; i < cpg * W; i += 256) {
+        int j = i / W, w = i - j * W;
+        gwc_lds[i] = tgt[chan0 + (size_t)j * HW + w];
+    }
+    __syncthreads();
+    const float fcpg = (float)cpg;
+    float *vrow = vol + (size_t)b * vol_bstride + (size_t)g * D * HW + (size_t)h * W;
+    for (int w = threadIdx.x; w < W; w += 256) {
+        float r[GWC_MAX_CPG];
+#pragma unroll
+        for (int j = 0; j < GWC_MAX_CPG; ++j) r[j] = j < cpg ? ref[chan0 + (size_t)j * HW + w] : 0.0f;
+        for (int d = 0; d < D; ++d) {
+            float out = 0.0f;
+            if (w >= d) {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < GWC_MAX_CPG; ++j)
+                    if (j < cpg) s = __fadd_rn(s, __fmul_rn(r[j], gwc_lds[j * W + w - d]));
+                out = __fdiv_rn(s, fcpg);
+            }
+            vrow[(size_t)d * HW + w] = out;
+        }
+    }
+}
+
+extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
+                              int B, int C, int H, int W, int D, int G, long vol_bstride,
+                              int device, void *stream) {
+    if (!ref || !tgt || !vol) return DKT_E_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0 || G <= 0) return DKT_E_SHAPE;
+    if (C % G != 0) return DKT_E_GROUPS;
+    const int cpg = C / G;
+    if (cpg > GWC_MAX_CPG) return DKT_E_UNSUPPORTED;
+    if (vol_bstride < (long)G * D * H * W) return DKT_E_SHAPE;
+    size_t lds = (size_t)cpg * W * sizeof(float);
+    if (lds > 160 * 1024) return DKT_E_UNSUPPORTED;
+    unsigned long long blocks = (unsigned long long)B * G * H;
+    if (blocks > 0x7FFFFFFFull) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)gwc_volume_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(gwc_volume_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
+                       ref, tgt, vol, C, H, W, D, G, vol_bstride);
+    return dkt_launch_status();
+}
+
+// One block per (b, c, h) source row; writes the D reference-half rows and the
+// D target-half rows that depend on it.  The source rows are read once.
+__global__ __launch_bounds__(256) void concat_volume_kernel(const float *__restrict__ ref,
+                                                            const float *__restrict__ tgt,
+                                                            float *__restrict__ vol, int C, int H, int W,
+                                                            int D, int ref_masked, long vol_bstride) {
+    const int h = blockIdx.x % H;
+    const int c = (blockIdx.x / H) % C;
+    const int b = blockIdx.x / (H * C);
+    const size_t HW = (size_t)H * W;
+    const size_t src = ((size_t)b * C + c) * HW + (size_t)h * W;
+    float *oref = vol + (size_t)b * vol_bstride + (size_t)c * D * HW + (size_t)h * W;
+    float *otgt = vol + (size_t)b * vol_bstride + (size_t)(C + c) * D * HW + (size_t)h * W;
+    for (int w = threadIdx.x; w < W; w += 256) {
+        const float rv = ref[src + w];
+        for (int d = 0; d < D; ++d) {
+            const bool in = w >= d;
+            // d >= W: python slices [d:] and [:-d] are empty -> plane stays zero,
+            // except the IGEV variant which assigns the whole reference plane.
+            oref[(size_t)d * HW + w] = (in || !ref_masked) ? rv : 0.0f;
+            otgt[(size_t)d * HW + w] = in ? tgt[src + w - d] : 0.0f;
+        }
+    }
+}
+
+extern "C" int dkt_concat_volume(const float *ref, const float *tgt, float *vol,
+                                 int B, int C, int H, int W, int D, int ref_masked, long vol_bstride,
+                                 int device, void *stream) {
+    if (!ref || !tgt || !vol) return DKT_E_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0) return DKT_E_SHAPE;
+    if (vol_bstride < 2L * C * D * H * W) return DKT_E_SHAPE;
+    unsigned long long blocks = (unsigned long long)B * C * H;
+    if (blocks > 0x7FFFFFFFull) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    hipLaunchKernelGGL(concat_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       ref, tgt, vol, C, H, W, D, ref_masked ? 1 : 0, vol_bstride);
+    return dkt_launch_status();
+}

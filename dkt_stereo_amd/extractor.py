@@ -1,0 +1,135 @@
+"""Feature / context encoders for the end-to-end harness.
+
+Out of scope for the HIP work (they run once per pair and are plain dense 2-D
+convolutions -> MIOpen), but the harness needs them to
+produce the feature maps and GRU context the hot path consumes, and published
+checkpoints must load: parameter names follow the reference's
+``core/extractor.py`` (``BasicEncoder`` :122-197, ``MultiBasicEncoder`` :199-300,
+``ResidualBlock`` :6-60).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _make_norm(kind, channels, groups=None):
+    if kind == 'group':
+        return nn.GroupNorm(num_groups=groups if groups else channels // 8, num_channels=channels)
+    if kind == 'batch':
+        return nn.BatchNorm2d(channels)
+    if kind == 'instance':
+        return nn.InstanceNorm2d(channels)
+    if kind == 'none':
+        return nn.Sequential()
+    raise ValueError("unknown norm_fn %r" % (kind,))
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_planes, planes, norm_fn='group', stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.norm1 = _make_norm(norm_fn, planes)
+        self.norm2 = _make_norm(norm_fn, planes)
+        self.downsample = None
+        if stride != 1 or in_planes != planes:
+            # the projection's norm is registered under both names, as upstream does
+            self.norm3 = _make_norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = F.relu(self.norm1(self.conv1(x)))
+        y = F.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return F.relu(x + y)
+
+
+def _stage(in_planes, planes, norm_fn, stride):
+    return nn.Sequential(ResidualBlock(in_planes, planes, norm_fn, stride=stride),
+                         ResidualBlock(planes, planes, norm_fn, stride=1))
+
+
+def _init_like_reference(module):
+    # core/extractor.py:150-157
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 1)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+class _Trunk(nn.Module):
+    """conv1/norm1 + layer1..3, shared by both encoders (1/2^downsample resolution)."""
+
+    def _build_trunk(self, norm_fn, downsample):
+        self.norm_fn = norm_fn
+        self.downsample = downsample
+        self.norm1 = _make_norm(norm_fn, 64, groups=8)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1 + (downsample > 2), padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = _stage(64, 64, norm_fn, 1)
+        self.layer2 = _stage(64, 96, norm_fn, 1 + (downsample > 1))
+        self.layer3 = _stage(96, 128, norm_fn, 1 + (downsample > 0))
+
+    def _trunk(self, x):
+        x = self.relu1(self.norm1(self.conv1(x)))
+        return self.layer3(self.layer2(self.layer1(x)))
+
+
+class BasicEncoder(_Trunk):
+    def __init__(self, output_dim=128, norm_fn='batch', dropout=0.0, downsample=3):
+        super().__init__()
+        self._build_trunk(norm_fn, downsample)
+        self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        _init_like_reference(self)
+
+    def forward(self, x, dual_inp=False):
+        pair = isinstance(x, (tuple, list))
+        if pair:
+            batch_dim = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        x = self.conv2(self._trunk(x))
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        if pair:
+            x = x.split(split_size=batch_dim, dim=0)
+        return x
+
+
+class MultiBasicEncoder(_Trunk):
+    def __init__(self, output_dim=[128], norm_fn='batch', dropout=0.0, downsample=3):
+        super().__init__()
+        self._build_trunk(norm_fn, downsample)
+        self.layer4 = _stage(128, 128, norm_fn, 2)
+        self.layer5 = _stage(128, 128, norm_fn, 2)
+        self.outputs08 = nn.ModuleList([
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), nn.Conv2d(128, dim[2], 3, padding=1))
+            for dim in output_dim])
+        self.outputs16 = nn.ModuleList([
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), nn.Conv2d(128, dim[1], 3, padding=1))
+            for dim in output_dim])
+        self.outputs32 = nn.ModuleList([nn.Conv2d(128, dim[0], 3, padding=1) for dim in output_dim])
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        _init_like_reference(self)
+
+    def forward(self, x, dual_inp=False, num_layers=3):
+        x = self._trunk(x)
+        v = None
+        if dual_inp:
+            v = x
+            x = x[:(x.shape[0] // 2)]
+        scales = [[f(x) for f in self.outputs08]]
+        if num_layers >= 2:
+            y = self.layer4(x)
+            scales.append([f(y) for f in self.outputs16])
+        if num_layers >= 3:
+            z = self.layer5(y)
+            scales.append([f(z) for f in self.outputs32])
+        if dual_inp:
+            scales.append(v)
+        return tuple(scales)

@@ -1,0 +1,117 @@
+"""End-to-end RAFT-Stereo inference harness around the HIP hot path.
+
+Counterpart of ``meta_arch/raft_stereo/raft_stereo.py`` (``RAFTStereo.forward``
+:85-187) with identical sub-module names -- ``cnet``, ``fnet``, ``update_block``,
+``context_zqr_convs`` -- hence identical ``state_dict()`` keys.  The reference's
+own ``RAFTStereo`` can equally be pointed at ``dkt_stereo_amd.corr`` /
+``dkt_stereo_amd.update``; this class exists so that the whole
+path can run, be timed and be parity-checked on a machine where the reference
+is not present.
+
+``forward(image1, image2, iters, flow_init, test_mode)`` follows the reference
+call convention (tools/evaluate_stereo.py:129).  Only ``test_mode=True`` is
+implemented: the HIP operators are inference-only.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .corr import CORR_IMPLEMENTATIONS
+from .extractor import BasicEncoder, MultiBasicEncoder
+from .update import BasicMultiUpdateBlock
+from .utils import coords_grid
+
+#: configs/raft_stereo/base.json of the reference
+BASE_CONFIG = dict(model="RAFTStereo", backbone_type="default", corr_implementation="reg",
+                   shared_backbone=False, corr_levels=4, corr_radius=4, n_downsample=2,
+                   context_norm="batch", slow_fast_gru=False, n_gru_layers=3,
+                   hidden_dims=[128, 128, 128], mixed_precision=False)
+
+
+def make_args(**overrides):
+    cfg = dict(BASE_CONFIG)
+    cfg.update(overrides)
+    return SimpleNamespace(**cfg)
+
+
+class RAFTStereo(nn.Module):
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args = args if args is not None else make_args()
+        if args.backbone_type != 'default' or args.shared_backbone:
+            raise NotImplementedError("harness covers the default two-encoder backbone "
+                                      "(configs/raft_stereo/base.json)")
+        context_dims = args.hidden_dims
+        self.cnet = MultiBasicEncoder(output_dim=[args.hidden_dims, context_dims],
+                                      norm_fn=args.context_norm, downsample=args.n_downsample)
+        self.update_block = BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims)
+        self.context_zqr_convs = nn.ModuleList(
+            [nn.Conv2d(context_dims[i], args.hidden_dims[i] * 3, 3, padding=3 // 2)
+             for i in range(args.n_gru_layers)])
+        self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', downsample=args.n_downsample)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    # -- pieces of the reference forward, split so the hot path can be timed alone --
+    def encode(self, image1, image2):
+        """raft_stereo.py:91-116: normalisation, encoders, context split."""
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        n = self.args.n_gru_layers
+        cnet_list = self.cnet(image1, num_layers=n)
+        fmap1, fmap2 = self.fnet([image1, image2])
+        net_list = [torch.tanh(x[0]) for x in cnet_list]
+        inp_list = [torch.relu(x[1]) for x in cnet_list]
+        inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+                    for i, conv in zip(inp_list, self.context_zqr_convs)]
+        return fmap1.float(), fmap2.float(), net_list, inp_list
+
+    def upsample_flow(self, flow, mask):
+        """raft_stereo.py:70-82, convex combination over a 3x3 neighbourhood."""
+        N, D, H, W = flow.shape
+        factor = 2 ** self.args.n_downsample
+        mask = torch.softmax(mask.view(N, 1, 9, factor, factor, H, W), dim=2)
+        up = F.unfold(factor * flow, [3, 3], padding=1).view(N, D, 9, 1, 1, H, W)
+        up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+        return up.reshape(N, D, factor * H, factor * W)
+
+    def iterate(self, fmap1, fmap2, net_list, inp_list, iters, flow_init=None):
+        """The hot path, raft_stereo.py:118-183 in test_mode: correlation build,
+        then `iters` x (lookup, update block), then convex upsampling."""
+        args = self.args
+        n = args.n_gru_layers
+        corr_block = CORR_IMPLEMENTATIONS[args.corr_implementation]
+        corr_fn = corr_block(fmap1, fmap2, radius=args.corr_radius, num_levels=args.corr_levels)
+        b, _, h, w = net_list[0].shape
+        coords0 = coords_grid(b, h, w).to(fmap1.device)
+        coords1 = coords0.clone()
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+        net_list = list(net_list)
+        up_mask = None
+        for itr in range(iters):
+            corr = corr_fn(coords1)
+            flow = coords1 - coords0
+            if n == 3 and args.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+            if n >= 2 and args.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=(n == 3), iter16=True, iter08=False, update=False)
+            net_list, up_mask, delta_flow = self.update_block(
+                net_list, inp_list, corr, flow, iter32=(n == 3), iter16=(n >= 2),
+                need_mask=(itr == iters - 1))
+            delta_flow[:, 1] = 0.0          # stereo: project onto the epipolar line
+            coords1 = coords1 + delta_flow
+        flow_up = self.upsample_flow(coords1 - coords0, up_mask)[:, :1]
+        return coords1 - coords0, flow_up
+
+    @torch.no_grad()
+    def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
+        if not test_mode:
+            raise NotImplementedError("dkt_stereo_amd.RAFTStereo is the inference (test_mode=True) path")
+        fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
+        return self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)

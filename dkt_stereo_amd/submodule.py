@@ -1,0 +1,86 @@
+"""Cost-volume builders with the reference's free-function signatures.
+
+``build_gwc_volume(ref, tgt, maxdisp, num_groups)`` is identical in
+meta_arch/igev_stereo/submodule.py:160-170, meta_arch/gwcnet/submodules.py:48-58
+and meta_arch/cgi/submodule.py.  ``build_concat_volume`` has two upstream
+definitions that differ in the reference half; both are here:
+
+    build_concat_volume          GwcNet semantics (gwcnet/submodules.py:25-36)
+    build_concat_volume_igev     IGEV copy       (igev_stereo/submodule.py:207-218)
+
+``build_gwc_concat_volume`` writes both into one (B, G+2C', D, H, W) buffer,
+replacing the torch.cat of gwc_main.py:315.
+"""
+import torch
+
+from . import _ffi
+
+
+def _check_pair(ref, tgt):
+    _ffi.require_gpu(ref, tgt)
+    _ffi.require_no_grad(ref, tgt)
+    if ref.shape != tgt.shape:
+        raise ValueError("feature maps disagree: %s vs %s" % (tuple(ref.shape), tuple(tgt.shape)))
+    return ref.contiguous(), tgt.contiguous()
+
+
+def _gwc_into(ref, tgt, vol, maxdisp, num_groups, bstride):
+    B, C, H, W = ref.shape
+    assert C % num_groups == 0  # groupwise_correlation, submodule.py:154
+    rc = _ffi.lib().dkt_gwc_volume(ref.data_ptr(), tgt.data_ptr(), vol.data_ptr(), B, C, H, W,
+                                   maxdisp, num_groups, bstride, _ffi.device_of(ref), _ffi.stream_of(ref))
+    _ffi.check(rc, "dkt_gwc_volume")
+
+
+def _concat_into(ref, tgt, vol, maxdisp, ref_masked, bstride):
+    B, C, H, W = ref.shape
+    rc = _ffi.lib().dkt_concat_volume(ref.data_ptr(), tgt.data_ptr(), vol.data_ptr(), B, C, H, W,
+                                      maxdisp, int(ref_masked), bstride,
+                                      _ffi.device_of(ref), _ffi.stream_of(ref))
+    _ffi.check(rc, "dkt_concat_volume")
+
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    ref, tgt = _check_pair(refimg_fea, targetimg_fea)
+    B, C, H, W = ref.shape
+    vol = torch.empty((B, num_groups, maxdisp, H, W), device=ref.device, dtype=torch.float32)
+    _gwc_into(ref, tgt, vol, maxdisp, num_groups, num_groups * maxdisp * H * W)
+    return vol
+
+
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
+    ref, tgt = _check_pair(refimg_fea, targetimg_fea)
+    B, C, H, W = ref.shape
+    vol = torch.empty((B, 2 * C, maxdisp, H, W), device=ref.device, dtype=torch.float32)
+    _concat_into(ref, tgt, vol, maxdisp, True, 2 * C * maxdisp * H * W)
+    return vol
+
+
+def build_concat_volume_igev(refimg_fea, targetimg_fea, maxdisp):
+    ref, tgt = _check_pair(refimg_fea, targetimg_fea)
+    B, C, H, W = ref.shape
+    vol = torch.empty((B, 2 * C, maxdisp, H, W), device=ref.device, dtype=torch.float32)
+    _concat_into(ref, tgt, vol, maxdisp, False, 2 * C * maxdisp * H * W)
+    return vol
+
+
+def build_gwc_concat_volume(gwc_ref, gwc_tgt, cat_ref, cat_tgt, maxdisp, num_groups):
+    """GWCNet.forward with use_concat_volume (gwc_main.py:310-315) in one buffer:
+    channels [0:G] group-wise correlation, [G:G+2C'] concat volume."""
+    gref, gtgt = _check_pair(gwc_ref, gwc_tgt)
+    cref, ctgt = _check_pair(cat_ref, cat_tgt)
+    B, _, H, W = gref.shape
+    Cc = cref.shape[1]
+    ch = num_groups + 2 * Cc
+    vol = torch.empty((B, ch, maxdisp, H, W), device=gref.device, dtype=torch.float32)
+    bstride = ch * maxdisp * H * W
+    _gwc_into(gref, gtgt, vol, maxdisp, num_groups, bstride)
+    _concat_into(cref, ctgt, vol[:, num_groups:], maxdisp, True, bstride)
+    return vol
+
+
+def disparity_regression(x, maxdisp):
+    """igev_stereo/submodule.py:220-224 (keepdim=True flavour)."""
+    assert len(x.shape) == 4
+    disp_values = torch.arange(0, maxdisp, dtype=x.dtype, device=x.device).view(1, maxdisp, 1, 1)
+    return torch.sum(x * disp_values, 1, keepdim=True)

@@ -1,0 +1,238 @@
+"""Update operator of RAFT-Stereo and IGEV-Stereo on MI355X.
+
+Mirrors the module/parameter names of the reference's ``core/update.py``
+(identical copy ``meta_arch/raft_stereo/update.py``) and
+``meta_arch/igev_stereo/update.py`` so that ``state_dict()`` keys match and
+published checkpoints load with ``strict=True``:
+
+    RAFT  : encoder.{convc1,convc2,convf1,convf2,conv}, gru08/gru16/gru32.{convz,convr,convq},
+            flow_head.{conv1,conv2}, mask.{0,2}
+    IGEV  : encoder.{convc1,convc2,convd1,convd2,conv}, gru04/gru08/gru16, disp_head, mask_feat_4.0
+
+What differs from the reference is how a GRU step is evaluated (core/update.py:23-32):
+  * convz and convr run as ONE convolution with concatenated output channels;
+  * the gate arithmetic is two fused HIP kernels (dkt_gru_gate_zr / _out) instead
+    of ~12 elementwise launches;
+  * r*h is written in place into the [h | x] buffer, so of the reference's three
+    torch.cat copies per GRU only the first remains.
+Convolutions go through ``dkt_stereo_amd.conv.conv2d`` (see that module).
+Inference only.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _ffi
+from .conv import conv2d
+
+
+def _batch_dense(t, hw):
+    """True when each batch element of a (B,C,H,W) tensor is one dense C*H*W block."""
+    return t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == hw
+
+
+class FlowHead(nn.Module):
+    """core/update.py:6-14."""
+
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=2):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
+
+    def forward(self, x):
+        return conv2d(conv2d(x, self.conv1, relu=True), self.conv2)
+
+
+class DispHead(FlowHead):
+    """meta_arch/igev_stereo/update.py:16-24."""
+
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=1):
+        super().__init__(input_dim, hidden_dim, output_dim)
+
+
+class ConvGRU(nn.Module):
+    """core/update.py:16-32 == meta_arch/igev_stereo/update.py:26-41."""
+
+    def __init__(self, hidden_dim, input_dim, kernel_size=3):
+        super().__init__()
+        pad = kernel_size // 2
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
+        self._zr_key = None
+        self._zr = None
+
+    def _merged_zr(self):
+        """convz | convr as one Conv2d-like (weight, bias) pair, rebuilt whenever
+        either parameter tensor is replaced or written (load_state_dict, .to())."""
+        wz, wr = self.convz.weight, self.convr.weight
+        key = (wz.data_ptr(), wr.data_ptr(), wz._version, wr._version,
+               self.convz.bias._version, self.convr.bias._version)
+        if key != self._zr_key:
+            with torch.no_grad():
+                self._zr = SimpleNamespace(
+                    weight=torch.cat([wz, wr], dim=0).contiguous(),
+                    bias=torch.cat([self.convz.bias, self.convr.bias], dim=0).contiguous(),
+                    padding=self.convz.padding)
+            self._zr_key = key
+        return self._zr
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        _ffi.require_gpu(h, cz, cr, cq, *x_list)
+        _ffi.require_no_grad(h, cz, cr, cq, *x_list)
+        B, Ch, H, W = h.shape
+        HW = H * W
+        L = _ffi.lib()
+        dev, st = _ffi.device_of(h), _ffi.stream_of(h)
+        if not _batch_dense(h, HW):
+            h = h.contiguous()
+        cz, cr, cq = [t if _batch_dense(t, HW) else t.contiguous() for t in (cz, cr, cq)]
+
+        hx = torch.cat([h, *x_list], dim=1)                       # [h | x]
+        azr = conv2d(hx, self._merged_zr())                       # (B, 2Ch, H, W)
+        z = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
+        # z = sigmoid(az+cz); r = sigmoid(ar+cr); hx[:, :Ch] <- r*h  (now [r*h | x])
+        rc = L.dkt_gru_gate_zr(azr.data_ptr(), cz.data_ptr(), cz.stride(0), cr.data_ptr(), cr.stride(0),
+                               h.data_ptr(), h.stride(0), z.data_ptr(), hx.data_ptr(), hx.stride(0),
+                               B, Ch, HW, dev, st)
+        _ffi.check(rc, "dkt_gru_gate_zr")
+        aq = conv2d(hx, self.convq)
+        out = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
+        # q = tanh(aq+cq); h' = (1-z)*h + z*q
+        rc = L.dkt_gru_gate_out(aq.data_ptr(), cq.data_ptr(), cq.stride(0), z.data_ptr(),
+                                h.data_ptr(), h.stride(0), out.data_ptr(), out.stride(0),
+                                B, Ch, HW, dev, st)
+        _ffi.check(rc, "dkt_gru_gate_out")
+        return out
+
+
+class BasicMotionEncoder(nn.Module):
+    """core/update.py:64-85 (RAFT).  ``cor_planes = corr_levels * (2*corr_radius+1)``."""
+
+    _branch = ("convf1", "convf2")
+    _cor_mult = 1
+    _aux_ch = 2
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) * self._cor_mult
+        self.convc1 = nn.Conv2d(cor_planes, 64, 1, padding=0)
+        self.convc2 = nn.Conv2d(64, 64, 3, padding=1)
+        setattr(self, self._branch[0], nn.Conv2d(self._aux_ch, 64, 7, padding=3))
+        setattr(self, self._branch[1], nn.Conv2d(64, 64, 3, padding=1))
+        self.conv = nn.Conv2d(64 + 64, 128 - self._aux_ch, 3, padding=1)
+
+    def forward(self, flow, corr):
+        cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
+        flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
+                     getattr(self, self._branch[1]), relu=True)
+        out = conv2d(torch.cat([cor, flo], dim=1), self.conv, relu=True)
+        return torch.cat([out, flow], dim=1)
+
+
+class BasicMotionEncoderIGEV(BasicMotionEncoder):
+    """meta_arch/igev_stereo/update.py:73-92: cor_planes = L*(2r+1)*(8+1), a
+    1-channel disparity branch (convd1/convd2) and a 127-channel output conv."""
+
+    _branch = ("convd1", "convd2")
+    _cor_mult = 9
+    _aux_ch = 1
+
+
+def pool2x(x):
+    """core/update.py:87-88."""
+    return F.avg_pool2d(x, 3, stride=2, padding=1)
+
+
+def interp(x, dest):
+    """core/update.py:93-95."""
+    return F.interpolate(x, dest.shape[2:], mode='bilinear', align_corners=True)
+
+
+class BasicMultiUpdateBlock(nn.Module):
+    """core/update.py:97-138 (RAFT-Stereo).  ``forward`` keeps the reference's
+    signature and, like it, updates the caller's ``net`` list in place.
+    Extra keyword ``need_mask`` (default True = reference behaviour): the harness
+    passes False on all but the last iteration of ``test_mode`` inference, where
+    the reference computes the up-sampling mask only to discard it
+    (raft_stereo.py:170-171)."""
+
+    def __init__(self, args, hidden_dims=[]):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        encoder_output_dim = 128
+        n = args.n_gru_layers
+        self.gru08 = ConvGRU(hidden_dims[2], encoder_output_dim + hidden_dims[1] * (n > 1))
+        self.gru16 = ConvGRU(hidden_dims[1], hidden_dims[0] * (n == 3) + hidden_dims[2])
+        self.gru32 = ConvGRU(hidden_dims[0], hidden_dims[1])
+        self.flow_head = FlowHead(hidden_dims[2], hidden_dim=256, output_dim=2)
+        factor = 2 ** self.args.n_downsample
+        self.mask = nn.Sequential(
+            nn.Conv2d(hidden_dims[2], 256, 3, padding=1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(256, (factor ** 2) * 9, 1, padding=0))
+
+    def _gru_stack(self, net, inp, fine, mid, coarse, motion, it_fine, it_mid, it_coarse):
+        n = self.args.n_gru_layers
+        if it_coarse:
+            net[2] = coarse(net[2], *(inp[2]), pool2x(net[1]))
+        if it_mid:
+            if n > 2:
+                net[1] = mid(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+            else:
+                net[1] = mid(net[1], *(inp[1]), pool2x(net[0]))
+        if it_fine:
+            mf = motion()
+            if n > 1:
+                net[0] = fine(net[0], *(inp[0]), mf, interp(net[1], net[0]))
+            else:
+                net[0] = fine(net[0], *(inp[0]), mf)
+        return net
+
+    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True,
+                update=True, need_mask=True):
+        net = self._gru_stack(net, inp, self.gru08, self.gru16, self.gru32,
+                              lambda: self.encoder(flow, corr), iter08, iter16, iter32)
+        if not update:
+            return net
+        delta_flow = self.flow_head(net[0])
+        mask = None
+        if need_mask:
+            # scale mask to balance gradients (core/update.py:137)
+            mask = .25 * conv2d(conv2d(net[0], self.mask[0], relu=True), self.mask[2])
+        return net, mask, delta_flow
+
+
+class BasicMultiUpdateBlockIGEV(BasicMultiUpdateBlock):
+    """meta_arch/igev_stereo/update.py:104-142: GRUs named gru04/gru08/gru16,
+    ``disp_head`` (1 channel) and ``mask_feat_4`` = conv3x3(128->32)+ReLU.
+    forward(net, inp, corr, disp, iter04, iter08, iter16, update) ->
+    (net, mask_feat_4, delta_disp)."""
+
+    def __init__(self, args, hidden_dims=[]):
+        nn.Module.__init__(self)
+        self.args = args
+        self.encoder = BasicMotionEncoderIGEV(args)
+        encoder_output_dim = 128
+        n = args.n_gru_layers
+        self.gru04 = ConvGRU(hidden_dims[2], encoder_output_dim + hidden_dims[1] * (n > 1))
+        self.gru08 = ConvGRU(hidden_dims[1], hidden_dims[0] * (n == 3) + hidden_dims[2])
+        self.gru16 = ConvGRU(hidden_dims[0], hidden_dims[1])
+        self.disp_head = DispHead(hidden_dims[2], hidden_dim=256, output_dim=1)
+        self.mask_feat_4 = nn.Sequential(
+            nn.Conv2d(hidden_dims[2], 32, 3, padding=1),
+            nn.ReLU(inplace=True))
+
+    def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True,
+                update=True, need_mask=True):
+        net = self._gru_stack(net, inp, self.gru04, self.gru08, self.gru16,
+                              lambda: self.encoder(disp, corr), iter04, iter08, iter16)
+        if not update:
+            return net
+        delta_disp = self.disp_head(net[0])
+        mask_feat_4 = conv2d(net[0], self.mask_feat_4[0], relu=True) if need_mask else None
+        return net, mask_feat_4, delta_disp

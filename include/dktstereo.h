@@ -1,0 +1,157 @@
+/*
+ * dktstereo.h -- C ABI of libdktstereo.so, the MI355X (gfx950) implementation of
+ * DKT-Stereo's stereo-inference hot path.
+ *
+ * The reference (jiaw-z/DKT-Stereo) is pure Python/PyTorch and has no FFI layer
+ * of its own; its seam for this path is Python duck typing.  The
+ * entry points below are therefore what a binding for that seam needs: one call
+ * per reference operator, plain device pointers and sizes, no torch types.  Each
+ * declaration cites the reference code it replaces (file:line relative to the
+ * reference tree).  dkt_stereo_amd/_ffi.py is the ctypes binding the reference's
+ * classes are re-exposed through; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (torch
+ *     tensors); the library never allocates, frees or retains caller memory;
+ *   - all tensors are float32, NCHW-contiguous unless a stride argument says
+ *     otherwise; strides are in ELEMENTS;
+ *   - `stream` is a hipStream_t (passed as void* so that C callers need no HIP
+ *     headers); work is enqueued stream-ordered, nothing synchronises;
+ *   - `device` is the HIP device ordinal the pointers live on, or -1 for "the
+ *     calling thread's current device" (nn.DataParallel drives replicas from
+ *     one Python thread per GPU, tools/ft_dkt.py:119);
+ *   - return 0 on success; negative = argument error detected on the host
+ *     before any launch (DKT_E_*); positive = a hipError_t from the launch.
+ *     Nothing throws, nothing exits.  dkt_strerror() names either kind;
+ *   - stateless and re-entrant: no globals besides read-only tables.
+ */
+#ifndef DKTSTEREO_H
+#define DKTSTEREO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DKT_ABI_VERSION 1
+#define DKT_MAX_LEVELS 8
+
+enum {
+    DKT_OK = 0,
+    DKT_E_NULL = -1,      /* null pointer argument */
+    DKT_E_SHAPE = -2,     /* non-positive or inconsistent dimension */
+    DKT_E_LEVELS = -3,    /* num_levels outside 1..DKT_MAX_LEVELS or level width reaches 0 */
+    DKT_E_RADIUS = -4,    /* radius outside 0..DKT_MAX_RADIUS */
+    DKT_E_GROUPS = -5,    /* channels not divisible by groups */
+    DKT_E_ALIGN = -6,     /* pointer/stride alignment requirement not met */
+    DKT_E_UNSUPPORTED = -7
+};
+#define DKT_MAX_RADIUS 8
+
+int dkt_version(void);
+const char *dkt_strerror(int rc);
+
+/* ---- RAFT-Stereo 1-D correlation --------------------------------------- */
+
+/* All-pairs 1-D correlation fused with the average-pool pyramid.
+ * Replaces CorrBlock1D.corr + the pyramid loop of CorrBlock1D.__init__
+ * (core/corr.py:148-156 and :111-125; same body meta_arch/raft_stereo/corr.py)
+ * and, with divisor = 1, Combined_Geo_Encoding_Volume.corr + its init_corr
+ * pyramid (meta_arch/igev_stereo/geometry.py:62-69, :27-29).
+ *   pyr[0][n, w2] = (sum_c f1[b,c,h,w1] * f2[b,c,h,w2]) / divisor,  n = (b*H+h)*W1+w1
+ *   (divisor = sqrt(C) as the reference divides, corr.py:156)
+ *   pyr[i][n, k]  = (pyr[i-1][n,2k] + pyr[i-1][n,2k+1]) * 0.5,  width W2>>i
+ * f1: (B,C,H,W1), f2: (B,C,H,W2); pyr: HOST array of L device pointers.
+ * Exact fp32 products and fp32 accumulation (v_mfma_f32_32x32x2_f32). */
+int dkt_corr1d_build(const float *f1, const float *f2, float *const *pyr,
+                     int B, int C, int H, int W1, int W2, int L, float divisor,
+                     int device, void *stream);
+
+/* Per-iteration pyramid lookup.  Replaces CorrBlock1D.__call__
+ * (core/corr.py:127-146) including its bilinear_sampler/grid_sample round trip
+ * (core/utils/utils.py:59-74) and the final permute(0,3,1,2).contiguous().
+ *   coords_x: x coordinates, element (b,h,w) at coords_x[b*coords_bstride + h*W1 + w]
+ *             (channel 0 of the (B,2,H,W) coords tensor: coords_bstride = 2*H*W1)
+ *   out: (B, L*(2r+1), H, W1), channel = level*(2r+1) + tap */
+int dkt_corr1d_lookup(const float *const *pyr, const float *coords_x, long coords_bstride,
+                      float *out, int B, int H, int W1, int W2, int L, int r,
+                      int device, void *stream);
+
+/* On-the-fly lookup without a volume.  Replaces PytorchAlternateCorrBlock1D
+ * (core/corr.py:64-107): samples the (i-times W-pooled) right feature map at
+ * the 2r+1 taps and dots it with the left feature vector, / sqrt(C).
+ * f2pyr: HOST array of L device pointers to (B,C,H,W2>>i) pooled right maps
+ * (built with dkt_pool_w).  coords: (B,2,H,W1) x and y planes. */
+int dkt_corr1d_lookup_otf(const float *f1, const float *const *f2pyr, const float *coords,
+                          float *out, int B, int C, int H, int W1, int W2, int L, int r,
+                          int device, void *stream);
+
+/* avg_pool2d(x,[1,2],stride=[1,2]) on rows: src (rows,W) -> dst (rows,W/2).
+ * core/corr.py:104, :124. */
+int dkt_pool_w(const float *src, float *dst, long rows, int W, int device, void *stream);
+
+/* L2 normalisation over channels, the prologue of CorrBlock1D_Cosine.corr
+ * (core/corr.py:201-202): dst[b,c,p] = src[b,c,p] / ||src[b,:,p]||_2 */
+int dkt_l2norm_channels(const float *src, float *dst, int B, int C, long HW,
+                        int device, void *stream);
+
+/* ---- IGEV combined geometry encoding volume ------------------------------ */
+
+/* Pairwise mean along D of a (B*C, D, HW) volume -> (B*C, D/2, HW): the
+ * geometry-volume pyramid of geometry.py:23-25 without the permute copy of :18. */
+int dkt_pool_d(const float *src, float *dst, long BC, int D, long HW, int device, void *stream);
+
+/* Replaces Combined_Geo_Encoding_Volume.__call__ (geometry.py:34-58).
+ *   geo_pyr[i]: (B,C,D>>i,H,W)  -- the network's native layout, read in place
+ *   init_pyr[i]: (B*H*W, W2>>i) -- from dkt_corr1d_build(divisor=1)
+ *   disp: (B,1,H,W); coords: (B,H,W,1) x positions (igev_stereo.py:195)
+ *   out: (B, L*K*(C+1), H, W), per level [c*K+k for c<C] then [init k] */
+int dkt_geo_lookup(const float *const *geo_pyr, const float *const *init_pyr,
+                   const float *disp, const float *coords, float *out,
+                   int B, int C, int D, int H, int W, int W2, int L, int r,
+                   int device, void *stream);
+
+/* ---- cost-volume builders -------------------------------------------------- */
+
+/* Replaces build_gwc_volume + groupwise_correlation
+ * (meta_arch/igev_stereo/submodule.py:152-170 == meta_arch/gwcnet/submodules.py:39-58).
+ *   vol[b,g,d,h,w] = mean_{c in group g} ref[b,c,h,w]*tgt[b,c,h,w-d] (w>=d) else 0
+ * vol_bstride: batch stride of vol in elements (G*D*H*W when dense; larger to
+ * write straight into a wider (B,G+2C',D,H,W) buffer, gwc_main.py:315). */
+int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
+                   int B, int C, int H, int W, int D, int G, long vol_bstride,
+                   int device, void *stream);
+
+/* Replaces build_concat_volume.  ref_masked = 1: GwcNet semantics
+ * (meta_arch/gwcnet/submodules.py:25-36, reference half only where w >= d);
+ * ref_masked = 0: IGEV copy (meta_arch/igev_stereo/submodule.py:207-218,
+ * reference half for every w).  vol: (B,2C,D,H,W) with batch stride vol_bstride. */
+int dkt_concat_volume(const float *ref, const float *tgt, float *vol,
+                      int B, int C, int H, int W, int D, int ref_masked, long vol_bstride,
+                      int device, void *stream);
+
+/* ---- ConvGRU gate fusions ---------------------------------------------------- */
+
+/* First gate stage of ConvGRU.forward (core/update.py:27-29 ==
+ * meta_arch/igev_stereo/update.py:37-39) given the raw outputs of the merged
+ * convz|convr convolution:
+ *   z  = sigmoid(azr[:, :Ch] + cz);  r = sigmoid(azr[:, Ch:] + cr);  rh = r * h
+ * azr: (B,2Ch,HW) dense.  cz, cr, h: (B,Ch,HW) with batch strides (context
+ * tensors are split views, raft_stereo.py:114).  z: dense (B,Ch,HW).
+ * rh: written with batch stride rh_bstride (straight into the first Ch channels
+ * of the [r*h | x] input buffer of convq, replacing the torch.cat of :29). */
+int dkt_gru_gate_zr(const float *azr, const float *cz, long cz_bstride,
+                    const float *cr, long cr_bstride, const float *h, long h_bstride,
+                    float *z, float *rh, long rh_bstride,
+                    int B, int Ch, long HW, int device, void *stream);
+
+/* Second gate stage (core/update.py:29-31): q = tanh(aq + cq);
+ * h' = (1 - z) * h + z * q.  hout may alias h. */
+int dkt_gru_gate_out(const float *aq, const float *cq, long cq_bstride,
+                     const float *z, const float *h, long h_bstride,
+                     float *hout, long hout_bstride,
+                     int B, int Ch, long HW, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DKTSTEREO_H */

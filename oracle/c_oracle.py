@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE -- numpy front-end to oracle/dkt_oracle.c (the plain-C
+restatement of the hot path's kernels).  See the header of dkt_oracle.c for
+what each entry restates (reference file:line) and how it is pinned.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libdkt_oracle.so")
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_lib = None
+
+
+def build(force=False):
+    """Compile dkt_oracle.c with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "dkt_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_bilinear_1d.restype = ctypes.c_float
+        _lib.orc_bilinear_1d.argtypes = [_f32p, ctypes.c_int, ctypes.c_float]
+    return _lib
+
+
+def _c(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _pp(arrs):
+    return (_f32p * len(arrs))(*[_p(a) for a in arrs])
+
+
+def bilinear_1d(row, x):
+    row = _c(row)
+    return float(lib().orc_bilinear_1d(_p(row), row.shape[0], ctypes.c_float(x)))
+
+
+def corr1d_build(f1, f2, num_levels, divide_by_sqrt_c=True):
+    """-> list of L arrays (B*H*W1, W2>>i).  core/corr.py:111-125,148-156."""
+    f1, f2 = _c(f1), _c(f2)
+    B, C, H, W1 = f1.shape
+    W2 = f2.shape[3]
+    pyr = [np.empty((B * H * W1, W2 >> i), np.float32) for i in range(num_levels)]
+    s = float(np.sqrt(np.float32(C))) if divide_by_sqrt_c else 0.0
+    lib().orc_corr1d_build(_p(f1), _p(f2), _pp(pyr), B, C, H, W1, W2, num_levels, ctypes.c_float(s))
+    return pyr
+
+
+def pool_pyramid(lvl0, num_levels):
+    lvl0 = _c(lvl0)
+    N, W2 = lvl0.shape
+    outs = [np.empty((N, W2 >> i), np.float32) for i in range(1, num_levels)]
+    if outs:
+        lib().orc_pool_pyramid(_p(lvl0), _pp(outs), ctypes.c_size_t(N), W2, num_levels)
+    return [lvl0] + outs
+
+
+def corr1d_lookup(pyr, coords, radius):
+    """coords (B,2,H,W) -> (B, L*K, H, W).  core/corr.py:127-146."""
+    pyr = [_c(p) for p in pyr]
+    coords = _c(coords)
+    B, _, H, W1 = coords.shape
+    L = len(pyr)
+    W2 = pyr[0].shape[1]
+    K = 2 * radius + 1
+    out = np.empty((B, L * K, H, W1), np.float32)
+    lib().orc_corr1d_lookup(_pp(pyr), _p(coords), _p(out), B, H, W1, W2, L, radius)
+    return out
+
+
+def corr1d_lookup_alt(f1, f2, coords, num_levels, radius):
+    """On-the-fly variant.  core/corr.py:64-107."""
+    f1, f2, coords = _c(f1), _c(f2), _c(coords)
+    B, C, H, W1 = f1.shape
+    W2 = f2.shape[3]
+    f2pyr = [f2]
+    for i in range(1, num_levels):
+        prev = f2pyr[-1]
+        w = prev.shape[3]
+        nxt = np.empty((B, C, H, w // 2), np.float32)
+        lib().orc_pool_rows(_p(prev), _p(nxt), ctypes.c_size_t(B * C * H), w)
+        f2pyr.append(nxt)
+    K = 2 * radius + 1
+    out = np.empty((B, num_levels * K, H, W1), np.float32)
+    lib().orc_corr1d_lookup_alt(_p(f1), _pp(f2pyr), _p(coords), _p(out), B, C, H, W1, W2, num_levels, radius)
+    return out
+
+
+def geo_pyramids(fmap1, fmap2, geo_volume, num_levels):
+    """Reference-layout pyramids.  meta_arch/igev_stereo/geometry.py:7-29."""
+    geo_volume = _c(geo_volume)
+    B, C, D, H, W = geo_volume.shape
+    g0 = np.empty((B * H * W * C, D), np.float32)
+    lib().orc_geo_permute(_p(geo_volume), _p(g0), B, C, D, H, W)
+    geo_pyr = pool_pyramid(g0, num_levels)
+    init_pyr = corr1d_build(fmap1, fmap2, num_levels, divide_by_sqrt_c=False)
+    return geo_pyr, init_pyr
+
+
+def geo_lookup(geo_pyr, init_pyr, disp, coords, C, radius):
+    """disp (B,1,H,W), coords (B,H,W,1) -> (B, L*K*(C+1), H, W).  geometry.py:34-58."""
+    geo_pyr = [_c(p) for p in geo_pyr]
+    init_pyr = [_c(p) for p in init_pyr]
+    disp, coords = _c(disp), _c(coords)
+    B, _, H, W = disp.shape
+    L = len(geo_pyr)
+    D = geo_pyr[0].shape[1]
+    W2 = init_pyr[0].shape[1]
+    K = 2 * radius + 1
+    out = np.empty((B, L * K * (C + 1), H, W), np.float32)
+    lib().orc_geo_lookup(_pp(geo_pyr), _pp(init_pyr), _p(disp), _p(coords), _p(out),
+                         B, C, D, H, W, W2, L, radius)
+    return out
+
+
+def gwc_volume(ref, tgt, maxdisp, num_groups):
+    ref, tgt = _c(ref), _c(tgt)
+    B, C, H, W = ref.shape
+    vol = np.empty((B, num_groups, maxdisp, H, W), np.float32)
+    lib().orc_gwc_volume(_p(ref), _p(tgt), _p(vol), B, C, H, W, maxdisp, num_groups)
+    return vol
+
+
+def concat_volume(ref, tgt, maxdisp, ref_masked):
+    ref, tgt = _c(ref), _c(tgt)
+    B, C, H, W = ref.shape
+    vol = np.empty((B, 2 * C, maxdisp, H, W), np.float32)
+    lib().orc_concat_volume(_p(ref), _p(tgt), _p(vol), B, C, H, W, maxdisp, int(ref_masked))
+    return vol
+
+
+def gru_gate_zr(az, ar, cz, cr, h):
+    az, ar, cz, cr, h = map(_c, (az, ar, cz, cr, h))
+    z = np.empty_like(h)
+    rh = np.empty_like(h)
+    lib().orc_gru_gate_zr(_p(az), _p(ar), _p(cz), _p(cr), _p(h), _p(z), _p(rh), ctypes.c_size_t(h.size))
+    return z, rh
+
+
+def gru_gate_out(aq, cq, z, h):
+    aq, cq, z, h = map(_c, (aq, cq, z, h))
+    out = np.empty_like(h)
+    lib().orc_gru_gate_out(_p(aq), _p(cq), _p(z), _p(h), _p(out), ctypes.c_size_t(h.size))
+    return out
+
+
+def conv2d_same(x, w, bias):
+    x, w = _c(x), _c(w)
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    y = np.empty((B, Cout, H, W), np.float32)
+    bp = _p(_c(bias)) if bias is not None else None
+    lib().orc_conv2d_same(_p(x), _p(w), bp, _p(y), B, Cin, H, W, Cout, KH, KW)
+    return y

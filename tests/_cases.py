@@ -1,0 +1,118 @@
+"""Parity cases: one definition shared by make_golden.py (which runs the imported
+reference on them and stores its outputs) and by the tests (which run the
+oracle / the HIP path on the same regenerated inputs)."""
+import numpy as np
+
+import _synth
+
+# ---- RAFT correlation build + lookup (core/corr.py:110-156) -----------------
+CORR_CASES = {
+    "small":  dict(seed=11, B=2, C=32, H=5, W=40, W2=40, L=4, r=4, hard=False),
+    "odd":    dict(seed=12, B=1, C=24, H=4, W=39, W2=39, L=3, r=4, hard=True),
+    "r3":     dict(seed=13, B=1, C=17, H=3, W=64, W2=64, L=2, r=3, hard=True),
+    "w1neW2": dict(seed=14, B=1, C=16, H=3, W=40, W2=52, L=3, r=4, hard=False),
+    "kitti":  dict(seed=15, B=1, C=256, H=2, W=312, W2=312, L=4, r=4, hard=False),
+    "tiny":   dict(seed=16, B=1, C=4, H=2, W=9, W2=9, L=1, r=1, hard=True),
+}
+
+
+def corr_inputs(c):
+    f1, f2 = _synth.fmap_pair(c["seed"], c["B"], c["C"], c["H"], c["W"], c["W2"])
+    mk = _synth.coords_hard if c["hard"] else _synth.coords
+    co = mk(c["seed"], c["B"], c["H"], c["W"])
+    return f1, f2, co
+
+
+# ---- IGEV geometry volume (meta_arch/igev_stereo/geometry.py) ------------------
+GEO_CASES = {
+    "small": dict(seed=21, B=1, Cm=24, C=8, D=16, H=4, W=40, L=2, r=4),
+    "b2":    dict(seed=22, B=2, Cm=16, C=8, D=12, H=3, W=25, L=2, r=4),
+    "l3":    dict(seed=23, B=1, Cm=8, C=4, D=24, H=2, W=48, L=3, r=2),
+}
+
+
+def geo_inputs(c):
+    m1, m2 = _synth.fmap_pair(c["seed"], c["B"], c["Cm"], c["H"], c["W"])
+    geo = _synth.normal((c["B"], c["C"], c["D"], c["H"], c["W"]), c["seed"], "geo")
+    disp = _synth.uniform((c["B"], 1, c["H"], c["W"]), -2.0, float(c["D"]) + 2.0, c["seed"], "disp")
+    disp[..., 0::5] = np.round(disp[..., 0::5])
+    coords = np.broadcast_to(np.arange(c["W"], dtype=np.float32).reshape(1, 1, c["W"], 1),
+                             (c["B"], c["H"], c["W"], 1)).copy()
+    return m1, m2, geo, disp, coords
+
+
+# ---- cost volumes ----------------------------------------------------------------
+GWC_CASES = {
+    "igev":  dict(seed=31, B=2, C=96, H=3, W=24, D=8, G=8),      # cpg 12
+    "gwc":   dict(seed=32, B=1, C=320, H=2, W=30, D=12, G=40),   # cpg 8
+    "dgtw":  dict(seed=33, B=1, C=8, H=2, W=6, D=9, G=2),        # D > W: empty slices
+    "g1":    dict(seed=34, B=1, C=5, H=2, W=17, D=4, G=1),
+}
+CONCAT_CASES = {
+    "gc":   dict(seed=41, B=2, C=12, H=3, W=24, D=8),
+    "dgtw": dict(seed=42, B=1, C=3, H=2, W=5, D=7),
+}
+
+
+def volume_inputs(c):
+    return _synth.fmap_pair(c["seed"], c["B"], c["C"], c["H"], c["W"])
+
+
+# ---- update operator -----------------------------------------------------------------
+GRU_CASES = {
+    "small": dict(seed=51, B=2, hidden=16, inputs=(24,), H=6, W=10),
+    "two_x": dict(seed=52, B=1, hidden=128, inputs=(128, 128), H=5, W=7),
+}
+
+
+def gru_inputs(c):
+    s = c["seed"]
+    shp = (c["B"], c["hidden"], c["H"], c["W"])
+    h = np.tanh(_synth.normal(shp, s, "h"))
+    czrq = _synth.normal((c["B"], 3 * c["hidden"], c["H"], c["W"]), s, "czrq", scale=0.5)
+    xs = [_synth.normal((c["B"], ci, c["H"], c["W"]), s, "x%d" % i) for i, ci in enumerate(c["inputs"])]
+    return h, czrq, xs
+
+
+UPDATE_CASES = {
+    # name: (flavour, n_gru_layers, slow_fast, H, W at the finest scale)
+    "raft3": dict(seed=61, igev=False, n=3, B=1, H=8, W=12),
+    "raft2": dict(seed=62, igev=False, n=2, B=2, H=8, W=12),
+    "raft1": dict(seed=63, igev=False, n=1, B=1, H=8, W=12),
+    "igev3": dict(seed=64, igev=True, n=3, B=1, H=8, W=12),
+}
+
+
+def update_cfg(c):
+    cfg = dict(corr_levels=2 if c["igev"] else 4, corr_radius=4, n_downsample=2,
+               n_gru_layers=c["n"], hidden_dims=[128, 128, 128], slow_fast_gru=False)
+    return cfg
+
+
+def update_inputs(c):
+    s, B, H, W = c["seed"], c["B"], c["H"], c["W"]
+    cfg = update_cfg(c)
+    K = 2 * cfg["corr_radius"] + 1
+    cor_planes = cfg["corr_levels"] * K * (9 if c["igev"] else 1)
+    net, inp = [], []
+    for i in range(3):
+        hh, ww = H >> i, W >> i
+        net.append(np.tanh(_synth.normal((B, 128, hh, ww), s, "net%d" % i)))
+        inp.append(_synth.normal((B, 384, hh, ww), s, "inp%d" % i, scale=0.5))
+    corr = _synth.normal((B, cor_planes, H, W), s, "corr")
+    flow = _synth.normal((B, 1 if c["igev"] else 2, H, W), s, "flow", scale=3.0)
+    return net, inp, corr, flow
+
+
+# ---- end to end ------------------------------------------------------------------------
+E2E_CASES = {
+    "64x128_it4":   dict(seed=0, B=1, H=64, W=128, iters=4, shift=12, stride=1),
+    "64x128_it12":  dict(seed=1, B=1, H=64, W=128, iters=12, shift=12, stride=1),
+    "256x512_it8":  dict(seed=0, B=1, H=256, W=512, iters=8, shift=12, stride=4),   # BASELINE cfg 1
+    "256x512_it32": dict(seed=2, B=1, H=256, W=512, iters=32, shift=40, stride=4),
+}
+E2E_WEIGHT_SEED = 7
+
+IGEV_LOOP_CASES = {
+    "small": dict(seed=71, B=1, Cm=24, C=8, D=16, H=8, W=16, iters=3),
+}
