@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/s of the RAFT-Stereo inference path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): RAFT-Stereo, 736x1248 KITTI-shape synthetic
+pair (D=192 range), 32 GRU iterations, batch 1 per GPU, fp32, random-init
+weights of the reference architecture, inputs resident in HBM before the timed
+region.  One "step" = one whole test_mode forward of one batch: both encoders,
+correlation-volume build, 32 x (pyramid lookup + update block), convex
+upsampling.  With N GPUs every rank runs its own pairs (weak scaling, no
+data-path collective); the final disparity maps are gathered to rank 0 over
+RCCL inside the timed region, as a real sharded evaluation would.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      the corr-lookup kernel (the kernel BASELINE.json's north_star sets
+                the HBM target for): algorithmic bytes per launch / its average
+                launch duration measured live with HIP events on the launch stream
+  cpu_baseline  oracle/torch_oracle.py (pure-PyTorch CPU port of the reference,
+                pinned to it by tests/golden) timed on this host, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--height", type=int, default=736)
+    p.add_argument("--width", type=int, default=1248)
+    p.add_argument("--iters", type=int, default=32)
+    p.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
+    p.add_argument("--cpu-iters", type=int, default=6, help="GRU iterations timed by the CPU baseline sample")
+    p.add_argument("--skip-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def lookup_bytes_per_launch(n_pixels, L=4, r=4):
+    """per pixel L*(K+1)*4 read + 4 (coord) + L*K*4 written = 308 B at L=4, r=4."""
+    K = 2 * r + 1
+    return n_pixels * (L * (K + 1) * 4 + 4 + L * K * 4)
+
+
+class TimedCorr:
+    """Wraps the corr object so every lookup launch is bracketed by HIP events on
+    the stream it is launched on (torch's current stream == the stream handed to
+    the C ABI)."""
+
+    def __init__(self, fn, sink):
+        self.fn, self.sink = fn, sink
+
+    def __call__(self, coords):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = self.fn(coords)
+        b.record()
+        self.sink.append((a, b))
+        return out
+
+
+def cpu_baseline(args, sd, cfg, i1, i2):
+    """Reference-equivalent CPU path (oracle/torch_oracle.py) on this host's cores.
+    Bounded sample: encoders + correlation build once, `cpu_iters` of the 32 GRU
+    iterations, extrapolated to 32 (every iteration does identical work)."""
+    from oracle import torch_oracle as to
+    cores = torch.get_num_threads()
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    a, b = i1[:1].cpu(), i2[:1].cpu()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        fmap1, fmap2, net, inp = to.raft_prepare(sd_cpu, cfg, a, b)
+        t1 = time.perf_counter()
+        to.raft_iterations(sd_cpu, cfg, fmap1, fmap2, net, inp, 1)          # warm-up (allocations, mkldnn primitives)
+        t2 = time.perf_counter()
+        to.raft_iterations(sd_cpu, cfg, fmap1, fmap2, net, inp, args.cpu_iters)
+        t3 = time.perf_counter()
+        to.raft_iterations(sd_cpu, cfg, fmap1, fmap2, net, inp, 1)
+        t4 = time.perf_counter()
+    once = t4 - t3                                  # corr build + 1 iteration + upsample
+    per_iter = max((t3 - t2) - once, 1e-9) / max(args.cpu_iters - 1, 1)
+    pair = (t1 - t0) + once + (args.iters - 1) * per_iter
+    return {"value": 1.0 / pair, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "1 pair %dx%d: encoders + corr build once, %d of %d GRU iterations timed "
+                      "(%.2f s/iter), extrapolated to %d" % (args.height, args.width, args.cpu_iters,
+                                                             args.iters, per_iter, args.iters),
+            "s_per_pair": pair, "s_per_iter": per_iter}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0 and world != 1:
+            print("warning: WORLD_SIZE %d != --gpus %d" % (world, args.gpus), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path in the product")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import _synth
+    from dkt_stereo_amd import _ffi
+    from dkt_stereo_amd.raft_stereo import BASE_CONFIG, RAFTStereo
+    from dkt_stereo_amd.shard import gather_disparity
+    _ffi.lib()                                   # fail loudly if the HIP library is missing
+    torch.backends.cudnn.benchmark = True       # MIOpen find mode, as tools/evaluate_stereo.py:113
+
+    model = RAFTStereo()
+    sd = _synth.torch_state_dict(_synth.shapes_of(model), 7)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    B = args.batch
+    # every rank gets its own pairs (seeded by global pair index)
+    pairs = [_synth.image_pair(1000 + rank * B + j, 1, args.height, args.width, 12 if j % 2 == 0 else 40)
+             for j in range(B)]
+    i1 = torch.cat([torch.from_numpy(p[0]) for p in pairs]).to(dev)
+    i2 = torch.cat([torch.from_numpy(p[1]) for p in pairs]).to(dev)
+    h4, w4 = args.height // 4, args.width // 4
+
+    look_events = []
+    import dkt_stereo_amd.raft_stereo as rs
+    real_impls = dict(rs.CORR_IMPLEMENTATIONS)
+
+    def timed_factory(cls):
+        def make(*a, **k):
+            return TimedCorr(cls(*a, **k), look_events)
+        return make
+
+    def step():
+        _, up = model(i1, i2, iters=args.iters, test_mode=True)
+        if world > 1:
+            up = gather_disparity(up, B * world, dst=0)
+        return up
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        rs.CORR_IMPLEMENTATIONS = {k: timed_factory(v) for k, v in real_impls.items()}
+        look_events.clear()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        rs.CORR_IMPLEMENTATIONS = real_impls
+
+        elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        elapsed = float(elapsed.item())
+        look_ms = [a.elapsed_time(b) for a, b in look_events]
+
+        # hot path alone (what the C ABI covers + the update block), encoders excluded
+        fmap1, fmap2, net, inp = model.encode(i1, i2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        model.iterate(fmap1, fmap2, net, inp, args.iters)
+        e1.record()
+        torch.cuda.synchronize()
+        hot_ms = e0.elapsed_time(e1)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_pix = B * h4 * w4
+    look_avg_ms = sum(look_ms) / max(len(look_ms), 1)
+    alg = lookup_bytes_per_launch(n_pix)
+    achieved = alg / (look_avg_ms * 1e-3) / 1e9 if look_avg_ms > 0 else 0.0
+    out = {
+        "metric": "stereo pairs/sec at 736x1248 D=192, 32 iters (RAFT-Stereo test_mode forward)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_iter": hot_ms / args.iters,
+        "hot_path_ms_per_pair": hot_ms / B,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded U[0,255) left image, shifted+noised right image; random-init weights)",
+        "config": {"workload": "RAFT-Stereo %dx%d (1/4 res %dx%d), D=192, %d GRU iters, batch %d/GPU, "
+                               "corr_implementation=reg, BASELINE.json configs[1]"
+                               % (args.height, args.width, h4, w4, args.iters, B),
+                   "parallelism": "dp%d (independent pairs per rank, result gather only)" % world,
+                   "conv_backend": "miopen-fp32"},
+        "roofline": {"kernel": "corr1d_lookup_kernel<4> (dkt_corr1d_lookup)", "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
+                     "launches_timed": len(look_ms),
+                     "note": "HIP events bracket each launch on its stream; event pairs add ~µs of "
+                             "marker overhead at this kernel size, see profiles/ for rocprofv3 durations"},
+    }
+    if not args.skip_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, sd, dict(BASE_CONFIG), i1, i2)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
