@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdktstereo.so")
 _c_f32p = ctypes.c_void_p
 _i, _l, _f, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 _pp = ctypes.POINTER(ctypes.c_void_p)
+_ip = ctypes.POINTER(ctypes.c_int)
+_lp = ctypes.POINTER(ctypes.c_long)
 
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
@@ -30,7 +32,13 @@ SIGNATURES = {
     "dkt_concat_volume": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _i, _vp],
     "dkt_gru_gate_zr": [_vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _i, _l, _i, _vp],
     "dkt_gru_gate_out": [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _i, _i, _l, _i, _vp],
+    "dkt_conv2d_packed_elems": [_ip, _i, _i, _i, _i],
+    "dkt_conv2d_pack_weights": [_vp, _ip, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp],
+    "dkt_conv2d_f16s": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
+                        _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
+#: entry points that do not return an int status
+RESTYPES = {"dkt_conv2d_packed_elems": ctypes.c_long}
 
 _lib = None
 
@@ -54,7 +62,7 @@ def lib():
         L.dkt_strerror.argtypes = [ctypes.c_int]
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
-            fn.restype = ctypes.c_int
+            fn.restype = RESTYPES.get(name, ctypes.c_int)
             fn.argtypes = argtypes
         _lib = L
     return _lib

@@ -1,22 +1,36 @@
 """Single entry point for every 2-D convolution on the hot path.
 
-``conv2d(x, layer, relu=False)`` takes anything with ``weight``/``bias``/
-``padding`` attributes (an ``nn.Conv2d`` or the merged z|r pair built by
-``ConvGRU``).  Backend ``"miopen"`` is the vendor convolution reached through
-``torch.nn.functional.conv2d`` (fp32, the parity path).  The update block's
-convolutions are ~98 % of an iteration; keeping them behind
-this one function is what lets later rounds swap in hand-written MFMA
-implicit-GEMM kernels without touching the operator code.
+``conv2d(x, layer, relu=False)``: ``x`` is a tensor or a LIST of tensors that the
+reference would ``torch.cat`` along channels first (core/update.py:24-25,29,83);
+``layer`` is anything with ``weight``/``bias``/``padding`` (an ``nn.Conv2d`` or
+the merged z|r pair built by ``ConvGRU``).
+
+Backends (``set_backend``):
+  "miopen"   vendor fp32 convolution via torch (concatenates list inputs). The
+             reference-class parity path.
+  "f16x3"    dkt_conv2d_f16s, passes=3: fp32 emulated on the fp16 matrix cores
+             with split operands (w_hi*x_hi + w_lo*x_hi + w_hi*x_lo, fp32
+             accumulate) -- ~22 bits per operand; list inputs are read in place.
+  "f16x2"    passes=2: activations rounded to fp16, weights split.
+  "f16"      passes=1: plain fp16 operands, fp32 accumulate.
+Kernel sizes other than 1x1 / 3x3 (the 7x7 flow stem with 1-2 input channels)
+and strided convolutions always use the vendor path.
 """
+import ctypes
+import math
+
 import torch
 import torch.nn.functional as F
 
+from . import _ffi
+
+_PASSES = {"f16x3": 3, "f16x2": 2, "f16": 1}
 _BACKEND = "miopen"
 
 
 def set_backend(name):
     global _BACKEND
-    if name not in ("miopen",):
+    if name != "miopen" and name not in _PASSES:
         raise ValueError("unknown conv backend %r" % (name,))
     _BACKEND = name
 
@@ -25,9 +39,84 @@ def get_backend():
     return _BACKEND
 
 
+def _vendor(x, layer, relu):
+    if isinstance(x, (list, tuple)):
+        x = x[0] if len(x) == 1 else torch.cat(list(x), dim=1)
+    y = F.conv2d(x, layer.weight, layer.bias, stride=1, padding=layer.padding)
+    return torch.relu_(y) if relu else y
+
+
+class _Packed:
+    __slots__ = ("key", "hi", "lo", "inv_scale", "bias")
+
+
+def _packed_weights(layer, src_channels):
+    """Split-fp16 weight image for dkt_conv2d_f16s, cached on the layer and rebuilt
+    when the parameter tensor is replaced or written."""
+    w = layer.weight
+    b = layer.bias
+    key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(src_channels))
+    cache = layer.__dict__.setdefault("_dkt_packed", {})
+    hit = cache.get(tuple(src_channels))
+    if hit is not None and hit.key == key:
+        return hit
+    cout, cin, kh, kw = w.shape
+    if cin != sum(src_channels):
+        raise ValueError("conv operands carry %d channels, layer expects %d" % (sum(src_channels), cin))
+    L = _ffi.lib()
+    n = len(src_channels)
+    ch = (ctypes.c_int * n)(*src_channels)
+    elems = L.dkt_conv2d_packed_elems(ch, n, cout, kh, kw)
+    if elems <= 0:
+        raise _ffi.DktError("dkt_conv2d_packed_elems rejected the layer shape")
+    wmax = float(w.detach().abs().max())
+    # power-of-two scale putting max|w| in [2^12, 2^13): keeps w_lo out of the fp16 subnormals
+    e = 12 - math.floor(math.log2(wmax)) if wmax > 0 else 0
+    scale = 2.0 ** e
+    p = _Packed()
+    p.hi = torch.empty(elems, device=w.device, dtype=torch.float16)
+    p.lo = torch.empty(elems, device=w.device, dtype=torch.float16)
+    wc = w.detach().float().contiguous()
+    rc = L.dkt_conv2d_pack_weights(wc.data_ptr(), ch, n, cout, kh, kw, scale, p.hi.data_ptr(), p.lo.data_ptr(),
+                                   _ffi.device_of(w), _ffi.stream_of(w))
+    _ffi.check(rc, "dkt_conv2d_pack_weights")
+    p.inv_scale = 1.0 / scale
+    p.bias = None if b is None else b.detach().float().contiguous()
+    p.key = key
+    cache[tuple(src_channels)] = p
+    return p
+
+
+def _dense(t):
+    hw = t.shape[2] * t.shape[3]
+    return t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == hw
+
+
 def conv2d(x, layer, relu=False):
+    kh, kw = layer.weight.shape[2:]
     pad = layer.padding
-    y = F.conv2d(x, layer.weight, layer.bias, stride=1, padding=pad)
-    if relu:
-        y = torch.relu_(y)
-    return y
+    pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+    hip_ok = (_BACKEND in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2))
+    if not hip_ok:
+        return _vendor(x, layer, relu)
+    srcs = list(x) if isinstance(x, (list, tuple)) else [x]
+    if len(srcs) > 4:
+        srcs = srcs[:3] + [torch.cat(srcs[3:], dim=1)]
+    _ffi.require_gpu(*srcs)
+    _ffi.require_no_grad(*srcs)
+    srcs = [s if _dense(s) else s.contiguous() for s in srcs]
+    B, _, H, W = srcs[0].shape
+    chans = [int(s.shape[1]) for s in srcs]
+    pk = _packed_weights(layer, chans)
+    cout = layer.weight.shape[0]
+    out = torch.empty((B, cout, H, W), device=srcs[0].device, dtype=torch.float32)
+    n = len(srcs)
+    ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    ch = (ctypes.c_int * n)(*chans)
+    bs = (ctypes.c_long * n)(*[s.stride(0) for s in srcs])
+    rc = _ffi.lib().dkt_conv2d_f16s(ptrs, ch, bs, n, pk.hi.data_ptr(), pk.lo.data_ptr(),
+                                    None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale,
+                                    out.data_ptr(), out.stride(0), B, H, W, cout, kh, kw, int(bool(relu)),
+                                    _PASSES[_BACKEND], _ffi.device_of(out), _ffi.stream_of(out))
+    _ffi.check(rc, "dkt_conv2d_f16s")
+    return out

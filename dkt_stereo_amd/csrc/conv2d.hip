@@ -1,0 +1,355 @@
+// conv2d.hip -- implicit-GEMM 2-D convolution for the update operator on gfx950.
+//
+// The ConvGRU / motion-encoder / head convolutions are ~98 % of a RAFT-Stereo
+// iteration (core/update.py:19-21, 72-76, 9-10, 111-113).  fp32 MFMA peaks at
+// 157 TFLOP/s on MI355X, 1/16 of the fp16 rate, so this kernel evaluates the
+// fp32 convolution on the fp16 matrix cores with SPLIT operands:
+//     w*s = w_hi + w_lo,  x = x_hi + x_lo   (each part fp16, s a power of two)
+//     w*x*s ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi      (fp32 accumulation)
+// which keeps ~22 significant bits per operand (fp32 has 24) at three
+// v_mfma_f32_32x32x16_f16 per product block: 833 TFLOP/s-equivalent peak, 5.3x
+// the fp32 pipe.  PASSES = 3 is that form; PASSES = 2 drops w_hi*x_lo (activations
+// rounded to fp16, weights still split); PASSES = 1 is plain fp16.  Each mode
+// is reported with its own measured deviation; the MIOpen fp32 path stays
+// available as the bit-for-bit-class parity path.
+//
+// GEMM view   D[co][px] = sum_{tap, ci} Wp[tap][ci][co] * X[ci][px + off(tap)]
+//   A = weights, pre-packed once per layer to [tap][ci/16][co][16] fp16 so a
+//       fragment (lane l: A[co = l&31][k = 8*(l>>5)..+7]) is one coalesced
+//       16-byte load per lane straight from L2 -- no LDS for weights;
+//   B = activations: NCHW fp32 in HBM (possibly several tensors = the
+//       reference's torch.cat operands, read in place), staged per 32-channel
+//       chunk as a (rows+halo) x (32+halo) pixel patch in LDS, converted to
+//       fp16 hi/lo and transposed to [pixel][channel] (pitch 80 B: conflict-
+//       free ds_read_b128 for the fragment lane l: B[k = 8*(l>>5)..+7][px = l&31]);
+//       each staged patch is reused by all taps and all output channels;
+//   D accumulators keep pixels along lanes (C/D map col = l&31), so output
+//       stores are 128-byte NCHW rows.
+// Block = 4 waves; wave tile 64 co x (2 rows x 32 cols); WM x WN waves along
+// (co, rows).  LDS is double buffered: the fp32 loads of chunk c+1 are in flight
+// under the MFMAs of chunk c; one barrier per chunk.
+#include "dkt_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CONV_MAX_SRC 4
+
+struct ConvArgs {
+    const float *src[CONV_MAX_SRC];
+    long src_bs[CONV_MAX_SRC];
+    int src_ch[CONV_MAX_SRC];
+    int nsrc;
+    const _Float16 *whi;
+    const _Float16 *wlo;
+    const float *bias;
+    float out_scale;  // 1/s
+    float *out;
+    long out_bs;
+    int H, W, Cout, CoutPad, nch16, tiles_w;
+    int relu;
+};
+
+__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
+    union { _Float16 h[2]; unsigned u; } v;
+    v.h[0] = a;
+    v.h[1] = b;
+    return v.u;
+}
+
+template <int KS, int WM, int WN, int PASSES>
+__global__ __launch_bounds__(256, WM == 2 ? 2 : 1) void conv2d_f16s_kernel(ConvArgs a) {
+    constexpr int HALO = KS / 2;
+    constexpr int TR = 2 * WN;               // output rows per block
+    constexpr int PR = TR + 2 * HALO;        // patch rows
+    constexpr int PC = 32 + 2 * HALO;        // patch cols
+    constexpr int NPP = PR * PC;             // patch pixels
+    constexpr int PITCH = 20;                // 32-bit words per pixel: 16 (32 fp16) + 4 pad
+    constexpr int PLANE = NPP * PITCH;       // words per (hi or lo) plane
+    constexpr int NPLANES = PASSES == 3 ? 2 : 1;   // x_lo is only needed for the w_hi*x_lo pass
+    constexpr int STAGE = PLANE * NPLANES;
+    constexpr int NITEMS = NPP * 16;         // (pixel, channel pair) items per chunk
+    constexpr int IT = (NITEMS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 2 * STAGE words
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int tile = blockIdx.x;
+    const int w0 = (tile % a.tiles_w) * 32;
+    const int h0 = (tile / a.tiles_w) * TR;
+    const int co_blk = blockIdx.y * (64 * WM);
+    const int b = blockIdx.z;
+    const long HW = (long)a.H * a.W;
+
+    // ---- per-thread staging plan (independent of the channel chunk) ----
+    int s_off[IT];        // offset inside a channel plane, or -1 when outside the image / unused
+    int s_lds[IT];        // LDS word index = pixel*PITCH + channel pair
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int item = tid + 256 * it;
+        const int cp = item / NPP, pp = item - cp * NPP;
+        const int pr = pp / PC, pc = pp - pr * PC;
+        const int ih = h0 - HALO + pr, iw = w0 - HALO + pc;
+        const bool ok = item < NITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        s_off[it] = ok ? ih * a.W + iw : -1;
+        s_lds[it] = item < NITEMS ? pp * PITCH + cp : -1;
+    }
+
+    float2 sreg[IT];
+    auto stage_load = [&](int chunk) {
+        // which source tensor holds this 32-channel chunk (wave-uniform scan)
+        int s = 0, c0 = chunk * 32;
+        while (s + 1 < a.nsrc && c0 >= ((a.src_ch[s] + 31) & ~31)) {
+            c0 -= (a.src_ch[s] + 31) & ~31;
+            ++s;
+        }
+        const float *base = a.src[s] + (long)b * a.src_bs[s] + (long)c0 * HW;
+        const int nch = a.src_ch[s] - c0;   // valid channels from c0 on (may exceed 32)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int ch = 2 * ((tid + 256 * it) / NPP);      // channel pair of this item
+            const bool ok = s_off[it] >= 0;
+            const long o = (long)ch * HW + (ok ? s_off[it] : 0);
+            float x0 = 0.0f, x1 = 0.0f;
+            if (ok && ch < nch) x0 = base[o];
+            if (ok && ch + 1 < nch) x1 = base[o + HW];
+            sreg[it] = make_float2(x0, x1);
+        }
+    };
+    auto stage_store = [&](unsigned *buf) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            if (s_lds[it] < 0) continue;
+            float x0 = fminf(fmaxf(sreg[it].x, -65504.0f), 65504.0f);
+            float x1 = fminf(fmaxf(sreg[it].y, -65504.0f), 65504.0f);
+            const _Float16 h0_ = (_Float16)x0, h1_ = (_Float16)x1;
+            buf[s_lds[it]] = pack_h2(h0_, h1_);
+            if (NPLANES == 2) {
+                const _Float16 l0 = (_Float16)(x0 - (float)h0_), l1 = (_Float16)(x1 - (float)h1_);
+                buf[PLANE + s_lds[it]] = pack_h2(l0, l1);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int li = lane & 31, kg = lane >> 5;
+    const int co_w = co_blk + wm * 64;                 // this wave's first output channel
+    // weight fragment base (halves): ((tap*nch16 + ch16)*CoutPad + co)*16 + kg*8
+    const long wlane = ((long)(co_w + li)) * 16 + kg * 8;
+    const int nchunks = a.nch16 / 2;
+
+    auto compute = [&](const unsigned *buf, int chunk) {
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const long wbase = ((long)tap * a.nch16 + (chunk * 2 + kh)) * a.CoutPad * 16 + wlane;
+                f16x8 ahi[2], alo[2], bhi[2], blo[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ahi[m] = *(const f16x8 *)(a.whi + wbase + m * 32 * 16);
+                    if (PASSES >= 2) alo[m] = *(const f16x8 *)(a.wlo + wbase + m * 32 * 16);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int pp = (wn * 2 + n + dy) * PC + li + dx;
+                    const unsigned *pb = buf + pp * PITCH + kh * 8 + kg * 4;
+                    bhi[n] = *(const f16x8 *)pb;
+                    if (NPLANES == 2) blo[n] = *(const f16x8 *)(pb + PLANE);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], bhi[n], acc[m][n], 0, 0, 0);
+                        if (PASSES >= 2)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], bhi[n], acc[m][n], 0, 0, 0);
+                        if (PASSES == 3)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], blo[n], acc[m][n], 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    stage_load(0);
+    stage_store(lds);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) stage_load(c + 1);
+        compute(lds + (c & 1) * STAGE, c);
+        if (more) stage_store(lds + ((c + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: un-scale, bias, optional ReLU, NCHW stores (128-byte rows) ----
+    float *ob = a.out + (long)b * a.out_bs;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int oh = h0 + wn * 2 + n, ow = w0 + li;
+            const bool pok = oh < a.H && ow < a.W;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_w + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (pok && co < a.Cout) {
+                    float v = acc[m][n][r] * a.out_scale + (a.bias ? a.bias[co] : 0.0f);
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    ob[(long)co * HW + (long)oh * a.W + ow] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Weight pre-pack: (Cout, Cin, KH, KW) fp32 -> hi/lo fp16, [tap][ci16][coPad][16],
+// with the input-channel axis re-chunked to match the per-source 32-channel
+// padding of the activation operands.  One thread per packed element.
+// ---------------------------------------------------------------------------
+struct PackArgs {
+    const float *w;
+    _Float16 *whi, *wlo;
+    int Cout, Cin, taps, CoutPad, nch16;
+    int src_ch[CONV_MAX_SRC];
+    int nsrc;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(PackArgs a) {
+    const long total = (long)a.taps * a.nch16 * a.CoutPad * 16;
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % 16);
+    const int co = (int)((i / 16) % a.CoutPad);
+    const int c16 = (int)((i / (16L * a.CoutPad)) % a.nch16);
+    const int tap = (int)(i / (16L * a.CoutPad * a.nch16));
+    // padded channel index -> (source, channel in source) -> original input channel
+    int pc = c16 * 16 + k, s = 0, cbase = 0;
+    while (s + 1 < a.nsrc && pc >= ((a.src_ch[s] + 31) & ~31)) {
+        pc -= (a.src_ch[s] + 31) & ~31;
+        cbase += a.src_ch[s];
+        ++s;
+    }
+    float v = 0.0f;
+    if (co < a.Cout && pc < a.src_ch[s]) v = a.w[((long)co * a.Cin + cbase + pc) * a.taps + tap] * a.scale;
+    const _Float16 hi = (_Float16)v;
+    a.whi[i] = hi;
+    a.wlo[i] = (_Float16)(v - (float)hi);
+}
+
+// output channels are tiled 64 per wave; layers wider than 64 use two waves (128) per block
+static int conv_cout_pad(int Cout) { return Cout <= 64 ? 64 : (Cout + 127) & ~127; }
+
+static int conv_padded_channels(const int *src_ch, int nsrc) {
+    int t = 0;
+    for (int s = 0; s < nsrc; ++s) t += (src_ch[s] + 31) & ~31;
+    return t;
+}
+
+extern "C" long dkt_conv2d_packed_elems(const int *src_channels, int nsrc, int Cout, int KH, int KW) {
+    if (!src_channels || nsrc < 1 || nsrc > CONV_MAX_SRC || Cout <= 0 || KH <= 0 || KW <= 0) return DKT_E_SHAPE;
+    const int cpad = conv_cout_pad(Cout);
+    return (long)KH * KW * (conv_padded_channels(src_channels, nsrc) / 16) * cpad * 16;
+}
+
+extern "C" int dkt_conv2d_pack_weights(const float *w, const int *src_channels, int nsrc,
+                                       int Cout, int KH, int KW, float scale,
+                                       void *w_hi, void *w_lo, int device, void *stream) {
+    if (!w || !src_channels || !w_hi || !w_lo) return DKT_E_NULL;
+    if (nsrc < 1 || nsrc > CONV_MAX_SRC || Cout <= 0 || KH <= 0 || KW != KH || !(scale > 0.0f)) return DKT_E_SHAPE;
+    PackArgs a;
+    a.w = w;
+    a.whi = (_Float16 *)w_hi;
+    a.wlo = (_Float16 *)w_lo;
+    a.Cout = Cout;
+    a.Cin = 0;
+    for (int s = 0; s < CONV_MAX_SRC; ++s) {
+        a.src_ch[s] = s < nsrc ? src_channels[s] : 0;
+        if (s < nsrc && src_channels[s] <= 0) return DKT_E_SHAPE;
+        a.Cin += a.src_ch[s];
+    }
+    a.nsrc = nsrc;
+    a.taps = KH * KW;
+    a.CoutPad = conv_cout_pad(Cout);
+    a.nch16 = conv_padded_channels(src_channels, nsrc) / 16;
+    a.scale = scale;
+    DKT_ENTER(device);
+    const long total = (long)a.taps * a.nch16 * a.CoutPad * 16;
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return dkt_launch_status();
+}
+
+template <int KS, int WM, int WN, int PASSES>
+static int launch_conv(const ConvArgs &a, int B, hipStream_t st) {
+    constexpr int HALO = KS / 2;
+    constexpr int NPP = (2 * WN + 2 * HALO) * (32 + 2 * HALO);
+    constexpr int STAGE = NPP * 20 * (PASSES == 3 ? 2 : 1);
+    const size_t lds = (size_t)2 * STAGE * sizeof(unsigned);
+    auto kern = conv2d_f16s_kernel<KS, WM, WN, PASSES>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int tiles_h = (a.H + 2 * WN - 1) / (2 * WN);
+    dim3 grid((unsigned)(a.tiles_w * tiles_h), (unsigned)((a.Cout + 64 * WM - 1) / (64 * WM)), (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    return dkt_launch_status();
+}
+
+template <int KS, int PASSES>
+static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
+    // narrow layers (<= 64 output channels) put all four waves along the rows
+    if (a.Cout <= 64) return launch_conv<KS, 1, 4, PASSES>(a, B, st);
+    return launch_conv<KS, 2, 2, PASSES>(a, B, st);
+}
+
+extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride,
+                               int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                               float out_scale, float *out, long out_bstride,
+                               int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
+                               int device, void *stream) {
+    if (!src || !src_channels || !src_bstride || !w_hi || !w_lo || !out) return DKT_E_NULL;
+    if (nsrc < 1 || nsrc > CONV_MAX_SRC || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || B > 65535) return DKT_E_SHAPE;
+    if (KH != KW || (KH != 1 && KH != 3)) return DKT_E_UNSUPPORTED;
+    if (passes < 1 || passes > 3) return DKT_E_UNSUPPORTED;
+    ConvArgs a;
+    for (int s = 0; s < CONV_MAX_SRC; ++s) {
+        a.src[s] = s < nsrc ? src[s] : nullptr;
+        a.src_bs[s] = s < nsrc ? src_bstride[s] : 0;
+        a.src_ch[s] = s < nsrc ? src_channels[s] : 0;
+        if (s < nsrc && (!src[s] || src_channels[s] <= 0)) return DKT_E_NULL;
+    }
+    a.nsrc = nsrc;
+    a.whi = (const _Float16 *)w_hi;
+    a.wlo = (const _Float16 *)w_lo;
+    a.bias = bias;
+    a.out_scale = out_scale;
+    a.out = out;
+    a.out_bs = out_bstride;
+    a.H = H; a.W = W; a.Cout = Cout;
+    a.CoutPad = conv_cout_pad(Cout);
+    a.nch16 = conv_padded_channels(src_channels, nsrc) / 16;
+    a.tiles_w = (W + 31) / 32;
+    a.relu = relu ? 1 : 0;
+    DKT_ENTER(device);
+    hipStream_t st = (hipStream_t)stream;
+    if (KH == 3) {
+        if (passes == 3) return launch_conv_shape<3, 3>(a, B, st);
+        if (passes == 2) return launch_conv_shape<3, 2>(a, B, st);
+        return launch_conv_shape<3, 1>(a, B, st);
+    }
+    if (passes == 3) return launch_conv_shape<1, 3>(a, B, st);
+    if (passes == 2) return launch_conv_shape<1, 2>(a, B, st);
+    return launch_conv_shape<1, 1>(a, B, st);
+}

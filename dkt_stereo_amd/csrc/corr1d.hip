@@ -62,15 +62,59 @@ __global__ __launch_bounds__(256) void corr1d_build_kernel(CorrBuildArgs a) {
     const int ma0 = m0 + li, ma1 = m0 + 32 + li;
     const int nb0 = n0 + li, nb1 = n0 + 32 + li;
     const bool va0 = ma0 < a.W1, va1 = ma1 < a.W1, vb0 = nb0 < a.W2, vb1 = nb1 < a.W2;
+    // branch-free edge handling: out-of-range lanes read a clamped (valid) column
+    // and their operand is zeroed afterwards, so every load is unconditional and
+    // the loads of group g+1 can be in flight under the MFMAs of group g.
+    const int ca0 = va0 ? ma0 : a.W1 - 1, ca1 = va1 ? ma1 : a.W1 - 1;
+    const int cb0 = vb0 ? nb0 : a.W2 - 1, cb1 = vb1 ? nb1 : a.W2 - 1;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     const int C2 = a.C & ~1;
-#pragma unroll 4
-    for (int c = 0; c < C2; c += 2) {
-        float a0 = va0 ? pa[ma0] : 0.0f;
-        float a1 = va1 ? pa[ma1] : 0.0f;
-        float b0 = vb0 ? pb[nb0] : 0.0f;
-        float b1 = vb1 ? pb[nb1] : 0.0f;
+    constexpr int P = 8;                         // channel pairs per software-pipeline stage
+    const int ngroups = (C2 / 2) / P;
+    float xa0[P], xa1[P], xb0[P], xb1[P];
+    if (ngroups > 0) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            xa0[j] = pa[(size_t)j * 2 * cs1 + ca0];
+            xa1[j] = pa[(size_t)j * 2 * cs1 + ca1];
+            xb0[j] = pb[(size_t)j * 2 * cs2 + cb0];
+            xb1[j] = pb[(size_t)j * 2 * cs2 + cb1];
+        }
+    }
+    for (int g = 0; g < ngroups; ++g) {
+        pa += (size_t)P * 2 * cs1;
+        pb += (size_t)P * 2 * cs2;
+        float ya0[P], ya1[P], yb0[P], yb1[P];
+        const bool more = g + 1 < ngroups;       // wave-uniform
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                ya0[j] = pa[(size_t)j * 2 * cs1 + ca0];
+                ya1[j] = pa[(size_t)j * 2 * cs1 + ca1];
+                yb0[j] = pb[(size_t)j * 2 * cs2 + cb0];
+                yb1[j] = pb[(size_t)j * 2 * cs2 + cb1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const float a0 = va0 ? xa0[j] : 0.0f, a1 = va1 ? xa1[j] : 0.0f;
+            const float b0 = vb0 ? xb0[j] : 0.0f, b1 = vb1 ? xb1[j] : 0.0f;
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                xa0[j] = ya0[j]; xa1[j] = ya1[j]; xb0[j] = yb0[j]; xb1[j] = yb1[j];
+            }
+        }
+    }
+    for (int c = ngroups * P * 2; c < C2; c += 2) {   // remaining pairs (C/2 not a multiple of P)
+        const float l0 = pa[ca0], l1 = pa[ca1], l2 = pb[cb0], l3 = pb[cb1];
+        const float a0 = va0 ? l0 : 0.0f, a1 = va1 ? l1 : 0.0f, b0 = vb0 ? l2 : 0.0f, b1 = vb1 ? l3 : 0.0f;
         acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
         acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
@@ -242,8 +286,101 @@ __global__ __launch_bounds__(256) void corr1d_lookup_kernel(LookupArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Lookup, cooperative form: FOUR lanes per (pixel, level).  The (2r+2)-float
+// window of a pixel sits inside 16 consecutive floats starting at the 16-byte
+// boundary below it; each of the four lanes fetches one aligned float4 of that
+// span (one 16-byte request instead of 2r+2 scalar requests that all hit the
+// same one or two cache lines), the span is parked in LDS (pitch 20 floats:
+// conflict-free for both the b128 writes and the scalar reads), and lane q then
+// evaluates taps q, q+4, q+8 with exactly the scalar kernel's arithmetic.
+// Row ends are masked by column index (zero padding), not by what was fetched.
+// Needs 2r+2 <= 13, i.e. r <= 5; other radii use the scalar kernel.
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void corr1d_lookup4_kernel(LookupArgs a) {
+    constexpr int K = 2 * R + 1;
+    constexpr int PITCH = 20;
+    __shared__ __attribute__((aligned(16))) float span[64 * PITCH];
+    const int q = threadIdx.x & 3;
+    const int g = threadIdx.x >> 2;                 // pixel slot in this block
+    const long p = blockIdx.x * 64L + g;
+    const int lv = blockIdx.y;
+    const int b = blockIdx.z;
+    const int wi = a.W2 >> lv;
+    const bool live = p < a.HW;
+    const long pc = live ? p : a.HW - 1;
+    const size_t n = (size_t)b * a.HW + pc;
+    const float *lvl = a.pyr.p[lv];
+    const float cx = a.coords_x[(size_t)b * a.coords_bstride + pc];
+    const float xc = __fdiv_rn(cx, (float)(1 << lv));
+    const float wm1 = (float)(wi - 1);
+    const float hwm1 = __fdiv_rn(wm1, 2.0f);
+    const DktTap t0 = dkt_tap(__fadd_rn((float)(-R), xc), wm1, hwm1);
+    const int i0 = dkt_clamp_idx(t0.fl, wi);
+    // element offsets inside this level's buffer
+    const long row0 = (long)n * wi;
+    const long e0 = row0 + i0;
+    const long eal = e0 & ~3L;                      // may be negative by up to 3 (+2 from i0>=-2)
+    const long nelem = ((long)gridDim.z * a.HW) * wi;
+    {
+        const long e = eal + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e >= 0 && e + 3 < nelem) {
+            v = *(const float4 *)(lvl + e);
+        } else {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (e + j >= 0 && e + j < nelem) ? lvl[e + j] : 0.0f;
+            v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        // zero everything that is not a column of THIS row
+        const long c0 = e - row0;
+        if (c0 < 0 || c0 >= wi) v.x = 0.0f;
+        if (c0 + 1 < 0 || c0 + 1 >= wi) v.y = 0.0f;
+        if (c0 + 2 < 0 || c0 + 2 >= wi) v.z = 0.0f;
+        if (c0 + 3 < 0 || c0 + 3 >= wi) v.w = 0.0f;
+        *(float4 *)(span + g * PITCH + 4 * q) = v;
+    }
+    __syncthreads();
+    if (!live) return;
+    const int m = (int)(e0 - eal);                   // 0..3: where the window starts in the span
+    const float *row = lvl + row0;
+    float *o = a.out + ((size_t)b * a.L * K + (size_t)lv * K) * a.HW + p;
+#pragma unroll
+    for (int j = 0; j < (K + 3) / 4; ++j) {
+        const int k = q + 4 * j;
+        if (k >= K) break;
+        const DktTap t = dkt_tap(__fadd_rn((float)(k - R), xc), wm1, hwm1);
+        const int ik = dkt_clamp_idx(t.fl, wi);
+        float v0, v1;
+        if (ik == i0 + k) {
+            v0 = span[g * PITCH + m + k];
+            v1 = span[g * PITCH + m + k + 1];
+        } else {
+            v0 = dkt_row_at(row, ik, wi);
+            v1 = dkt_row_at(row, ik + 1, wi);
+        }
+        o[(size_t)k * a.HW] = dkt_blend(v0, v1, t);
+    }
+}
+
+// Tuning knob (read per call, read-only): DKT_LOOKUP_VARIANT=1 selects the
+// one-thread-per-(pixel,level) kernel, anything else the 4-lane cooperative one.
+static int dkt_lookup_variant() {
+    const char *s = getenv("DKT_LOOKUP_VARIANT");
+    return s ? atoi(s) : 4;
+}
+
 template <int R>
 static void launch_lookup(const LookupArgs &a, int B, hipStream_t st) {
+    if constexpr (2 * R + 2 <= 13) {
+        if (dkt_lookup_variant() == 4) {
+            dim3 grid((unsigned)((a.HW + 63) / 64), (unsigned)a.L, (unsigned)B);
+            hipLaunchKernelGGL(corr1d_lookup4_kernel<R>, grid, dim3(256), 0, st, a);
+            return;
+        }
+    }
     dim3 grid((unsigned)((a.HW + 255) / 256), (unsigned)a.L, (unsigned)B);
     hipLaunchKernelGGL(corr1d_lookup_kernel<R>, grid, dim3(256), 0, st, a);
 }

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import conv2d
+from .conv import conv2d, get_backend
 
 
 def _batch_dense(t, hw):
@@ -90,15 +90,23 @@ class ConvGRU(nn.Module):
             h = h.contiguous()
         cz, cr, cq = [t if _batch_dense(t, HW) else t.contiguous() for t in (cz, cr, cq)]
 
-        hx = torch.cat([h, *x_list], dim=1)                       # [h | x]
-        azr = conv2d(hx, self._merged_zr())                       # (B, 2Ch, H, W)
+        if get_backend() == "miopen":
+            # vendor convolutions want one dense operand: build [h | x] once and
+            # let the gate kernel overwrite its first Ch channels with r*h
+            hx = torch.cat([h, *x_list], dim=1)
+            zr_in, rh, q_in = hx, hx, hx
+        else:
+            # own convolution kernel reads the cat operands in place: no copies
+            rh = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
+            zr_in, q_in = [h, *x_list], [rh, *x_list]
+        azr = conv2d(zr_in, self._merged_zr())                    # (B, 2Ch, H, W)
         z = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
-        # z = sigmoid(az+cz); r = sigmoid(ar+cr); hx[:, :Ch] <- r*h  (now [r*h | x])
+        # z = sigmoid(az+cz); r = sigmoid(ar+cr); rh <- r*h
         rc = L.dkt_gru_gate_zr(azr.data_ptr(), cz.data_ptr(), cz.stride(0), cr.data_ptr(), cr.stride(0),
-                               h.data_ptr(), h.stride(0), z.data_ptr(), hx.data_ptr(), hx.stride(0),
+                               h.data_ptr(), h.stride(0), z.data_ptr(), rh.data_ptr(), rh.stride(0),
                                B, Ch, HW, dev, st)
         _ffi.check(rc, "dkt_gru_gate_zr")
-        aq = conv2d(hx, self.convq)
+        aq = conv2d(q_in, self.convq)
         out = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
         # q = tanh(aq+cq); h' = (1-z)*h + z*q
         rc = L.dkt_gru_gate_out(aq.data_ptr(), cq.data_ptr(), cq.stride(0), z.data_ptr(),
@@ -129,7 +137,7 @@ class BasicMotionEncoder(nn.Module):
         cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
         flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
                      getattr(self, self._branch[1]), relu=True)
-        out = conv2d(torch.cat([cor, flo], dim=1), self.conv, relu=True)
+        out = conv2d([cor, flo], self.conv, relu=True)
         return torch.cat([out, flow], dim=1)
 
 

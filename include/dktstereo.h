@@ -151,6 +151,31 @@ int dkt_gru_gate_out(const float *aq, const float *cq, long cq_bstride,
                      float *hout, long hout_bstride,
                      int B, int Ch, long HW, int device, void *stream);
 
+/* ---- update-operator convolutions ------------------------------------------------ */
+
+/* nn.Conv2d (stride 1, "same" zero padding, 1x1 or 3x3) as used by ConvGRU,
+ * BasicMotionEncoder, FlowHead/DispHead and the mask heads (core/update.py:9-10,
+ * 19-21, 72-76, 111-113; meta_arch/igev_stereo/update.py same lines), evaluated
+ * as an implicit GEMM on the fp16 matrix cores with split operands and fp32
+ * accumulation (see conv2d.hip).  `src` are up to DKT_CONV_MAX_SRC NCHW fp32
+ * tensors that the reference concatenates along channels before the
+ * convolution (torch.cat at core/update.py:24-25,29,83) -- they are read in
+ * place.  passes: 3 = w_hi*x_hi + w_lo*x_hi + w_hi*x_lo (fp32-class accuracy),
+ * 2 = activations rounded to fp16, 1 = plain fp16.
+ *   out[b,co,h,w] = out_scale * acc + bias[co], optional ReLU; (B,Cout,H,W) with
+ *   batch stride out_bstride.
+ * The weights must have been packed by dkt_conv2d_pack_weights with the SAME
+ * src_channels list (scale = 1/out_scale, a power of two). */
+#define DKT_CONV_MAX_SRC 4
+long dkt_conv2d_packed_elems(const int *src_channels, int nsrc, int Cout, int KH, int KW);
+int dkt_conv2d_pack_weights(const float *w /* (Cout,sum(src_channels),KH,KW) */,
+                            const int *src_channels, int nsrc, int Cout, int KH, int KW, float scale,
+                            void *w_hi /* fp16[packed_elems] */, void *w_lo, int device, void *stream);
+int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride, int nsrc,
+                    const void *w_hi, const void *w_lo, const float *bias, float out_scale,
+                    float *out, long out_bstride, int B, int H, int W, int Cout, int KH, int KW,
+                    int relu, int passes, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,148 @@
+"""-m gpu: the split-fp16 implicit-GEMM convolution (dkt_conv2d_f16s) against an fp64
+reference of nn.Conv2d, alone and inside the update operator / the full
+RAFT-Stereo loop.  Tolerances, relative to max|y|:
+   passes=3 (w_hi*x_hi + w_lo*x_hi + w_hi*x_lo):  2e-6   (fp32-class)
+   passes=2 (activations rounded to fp16)       :  1e-3
+   passes=1 (plain fp16 operands)               :  3e-3
+End to end the passes=3 backend must meet north_star's 1e-3 max-abs on the final
+disparity against the reference's outputs (tests/golden)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _cases
+import _synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REL = {"f16x3": 2e-6, "f16x2": 1e-3, "f16": 3e-3}
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(autouse=True)
+def _restore_backend():
+    from dkt_stereo_amd import conv
+    prev = conv.get_backend()
+    yield
+    conv.set_backend(prev)
+
+
+SHAPES = [
+    # name, B, src channels, Cout, H, W, k, relu
+    ("k3_small", 2, [16], 40, 9, 37, 3, False),
+    ("k3_cat3", 1, [128, 128, 128], 256, 10, 45, 3, False),      # gru08 z|r shape
+    ("k3_cat_odd", 1, [7, 33, 64], 126, 6, 33, 3, True),         # ragged sources, Cout not /64
+    ("k3_narrow", 2, [64], 64, 17, 70, 3, True),                 # WM=1 layout (encoder 64->64)
+    ("k3_cout2", 1, [256], 2, 8, 40, 3, False),                  # flow head conv2
+    ("k1_corr", 2, [36], 64, 7, 50, 1, True),                    # encoder convc1
+    ("k1_mask", 1, [256], 144, 5, 33, 1, False),                 # mask head 1x1
+    ("k3_tiny", 1, [3], 5, 2, 3, 3, False),                      # smaller than one tile
+]
+
+
+@pytest.mark.parametrize("backend", ["f16x3", "f16x2", "f16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+@torch.no_grad()
+def test_conv_vs_fp64(shape, backend):
+    from dkt_stereo_amd import conv
+    name, B, chans, cout, H, W, k, relu = shape
+    cin = sum(chans)
+    layer = torch.nn.Conv2d(cin, cout, k, padding=k // 2)
+    bnd = 1.0 / np.sqrt(cin * k * k)
+    layer.weight.data = G(_synth.uniform((cout, cin, k, k), -bnd, bnd, 90, name, "w"))
+    layer.bias.data = G(_synth.uniform((cout,), -bnd, bnd, 90, name, "b"))
+    layer.to(DEV)
+    xs = [G(_synth.normal((B, c, H, W), 90, name, "x%d" % i, scale=1.5)) for i, c in enumerate(chans)]
+    ref = F.conv2d(torch.cat(xs, 1).double(), layer.weight.double(), layer.bias.double(), padding=k // 2)
+    if relu:
+        ref = ref.clamp_min(0)
+    conv.set_backend(backend)
+    got = conv.conv2d(xs if len(xs) > 1 else xs[0], layer, relu=relu)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    err = float((got.double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    print("%s %s: max err %.3e (rel %.2e)" % (name, backend, err, err / scale))
+    assert err <= REL[backend] * scale
+    # strided batch operand (a channel slice of a wider tensor) is read in place
+    wide = torch.zeros(B, chans[0] + 3, H, W, device=DEV)
+    wide[:, 1:1 + chans[0]] = xs[0]
+    got2 = conv.conv2d([wide[:, 1:1 + chans[0]]] + xs[1:], layer, relu=relu)
+    assert torch.equal(got2, got)
+
+
+@torch.no_grad()
+def test_conv_weight_cache_invalidation():
+    from dkt_stereo_amd import conv
+    conv.set_backend("f16x3")
+    layer = torch.nn.Conv2d(32, 64, 3, padding=1).to(DEV)
+    x = G(_synth.normal((1, 32, 8, 40), 91, "x"))
+    a = conv.conv2d(x, layer)
+    layer.weight.data.mul_(2.0)          # in-place write bumps the version counter
+    layer.bias.data.zero_()
+    b = conv.conv2d(x, layer)
+    ref = F.conv2d(x.double(), layer.weight.double(), None, padding=1)
+    assert float((b.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", list(_cases.UPDATE_CASES))
+@torch.no_grad()
+def test_update_block_f16x3(name, golden):
+    from dkt_stereo_amd import conv
+    from test_gpu_parity import _make_block, maxabs
+    conv.set_backend("f16x3")
+    c = _cases.UPDATE_CASES[name]
+    blk, _ = _make_block(c)
+    net, inp, corr, flow = _cases.update_inputs(c)
+    n = c["n"]
+    gnet = [G(x) for x in net]
+    ginp = [list(G(x).split(128, dim=1)) for x in inp]
+    kw = dict(iter16=(n == 3), iter08=(n >= 2)) if c["igev"] else dict(iter32=(n == 3), iter16=(n >= 2))
+    rnet, rmask, rdelta = blk(gnet, ginp, G(corr), G(flow), **kw)
+    g = golden("update")
+    for i in range(3):
+        assert maxabs(rnet[i], g["%s/net%d" % (name, i)]) <= 1e-5
+    assert maxabs(rmask[:, :, ::2, ::2], g[name + "/mask"]) <= 5e-5
+    assert maxabs(rdelta, g[name + "/delta"]) <= 5e-5
+
+
+@pytest.mark.parametrize("name", list(_cases.E2E_CASES))
+@torch.no_grad()
+def test_raft_stereo_end_to_end_f16x3(name, golden):
+    from dkt_stereo_amd import conv
+    from test_gpu_parity import _raft, maxabs
+    conv.set_backend("f16x3")
+    c = _cases.E2E_CASES[name]
+    model, _ = _raft()
+    i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+    lo, up = model(G(i1), G(i2), iters=c["iters"], test_mode=True)
+    g = golden("raft_e2e")
+    s = int(g[name + "/stride"])
+    d_up = maxabs(up[:, :, ::s, ::s], g[name + "/flow_up"])
+    epe = float(np.mean(np.abs(up[:, :, ::s, ::s].cpu().numpy() - g[name + "/flow_up"])))
+    print("%s f16x3: max|d_up| %.3e EPE %.3e" % (name, d_up, epe))
+    assert d_up <= 1e-3 and epe <= 1e-3
+
+
+@pytest.mark.parametrize("backend", ["f16x2", "f16"])
+@torch.no_grad()
+def test_reduced_pass_backends_report_their_deviation(backend, golden):
+    """The cheaper modes are not parity paths; this records how far they drift on
+    the 32-iteration fixture and only guards against gross breakage."""
+    from dkt_stereo_amd import conv
+    from test_gpu_parity import _raft, maxabs
+    conv.set_backend(backend)
+    c = _cases.E2E_CASES["256x512_it32"]
+    model, _ = _raft()
+    i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+    _, up = model(G(i1), G(i2), iters=c["iters"], test_mode=True)
+    g = golden("raft_e2e")
+    s = int(g["256x512_it32/stride"])
+    d = maxabs(up[:, :, ::s, ::s], g["256x512_it32/flow_up"])
+    epe = float(np.mean(np.abs(up[:, :, ::s, ::s].cpu().numpy() - g["256x512_it32/flow_up"])))
+    print("256x512_it32 %s: max|d_up| %.3e EPE %.3e" % (backend, d, epe))
+    assert d <= 0.5

@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmarks on one MI355X (run through gpurun).  Every number
+is HIP-event time over N back-to-back launches on torch's current stream
+(the stream handed to the C ABI), reported per launch together with the
+algorithmic bytes / flops of SURVEY.md section 8d.
+
+    python tools/bench_kernels.py [lookup] [build] [gates] [conv] [e2e] [autocast] [volumes]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _synth  # noqa: E402
+
+DEV = "cuda:0"
+RESULTS = {}
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def timeit(fn, n=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3     # microseconds
+
+
+def report(name, us, bytes_=None, flops=None):
+    line = "%-44s %10.2f us" % (name, us)
+    r = {"us": us}
+    if bytes_:
+        r["GBps"] = bytes_ / us / 1e3
+        line += "  %8.1f GB/s (%.1f%% of 8 TB/s)" % (r["GBps"], r["GBps"] / 80.0)
+    if flops:
+        r["TFLOPs"] = flops / us / 1e6
+        line += "  %8.1f TFLOP/s" % r["TFLOPs"]
+    RESULTS[name] = r
+    print(line, flush=True)
+
+
+@torch.no_grad()
+def bench_lookup():
+    from dkt_stereo_amd.corr import CorrBlock1D
+    for B in (1, 8):
+        H, W, C = 184, 312, 256
+        f1, f2 = (torch.randn(B, C, H, W, device=DEV) for _ in range(2))
+        blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+        n = B * H * W
+        alg = n * 308
+        for kind in ("smooth", "random"):
+            coords = torch.zeros(B, 2, H, W, device=DEV)
+            xs = torch.arange(W, device=DEV).float().view(1, 1, W)
+            if kind == "smooth":
+                coords[:, 0] = xs - 20.3 - 3.0 * torch.sin(torch.arange(H, device=DEV).float() / 9.0).view(1, H, 1)
+            else:
+                coords[:, 0] = xs - 60.0 * torch.rand(B, H, W, device=DEV)
+            for variant in ("1", "4"):
+                os.environ["DKT_LOOKUP_VARIANT"] = variant
+                report("lookup v%s B=%d %s" % (variant, B, kind), timeit(lambda: blk(coords), n=200), bytes_=alg)
+        os.environ.pop("DKT_LOOKUP_VARIANT", None)
+        del blk, f1, f2
+
+
+@torch.no_grad()
+def bench_build():
+    from dkt_stereo_amd.corr import CorrBlock1D
+    B, C, H, W = 1, 256, 184, 312
+    f1, f2 = (torch.randn(B, C, H, W, device=DEV) for _ in range(2))
+    fl = 2.0 * B * H * W * W * C
+    by = 2 * B * C * H * W * 4 + B * H * W * 4 * sum(W >> i for i in range(4))
+    report("corr1d_build cfg2", timeit(lambda: CorrBlock1D(f1, f2, num_levels=4, radius=4), n=20), bytes_=by, flops=fl)
+    report("torch einsum+pools (rocBLAS) cfg2",
+           timeit(lambda: _torch_build(f1, f2), n=10), flops=fl)
+
+
+def _torch_build(f1, f2):
+    b, c, h, w = f1.shape
+    vol = torch.einsum('aijk,aijh->ajkh', f1, f2).reshape(b * h * w, 1, 1, w) / 16.0
+    out = [vol]
+    for _ in range(3):
+        vol = F.avg_pool2d(vol, [1, 2], stride=[1, 2])
+        out.append(vol)
+    return out
+
+
+@torch.no_grad()
+def bench_gates():
+    from dkt_stereo_amd import _ffi
+    L = _ffi.lib()
+    B, Ch, H, W = 1, 128, 184, 312
+    HW = H * W
+    azr = torch.randn(B, 2 * Ch, H, W, device=DEV)
+    ctx = torch.randn(B, 3 * Ch, H, W, device=DEV)
+    cz, cr, cq = ctx.split(Ch, dim=1)
+    h = torch.tanh(torch.randn(B, Ch, H, W, device=DEV))
+    z = torch.empty_like(h)
+    rh = torch.empty_like(h)
+    aq = torch.randn_like(h)
+    out = torch.empty_like(h)
+    st = _ffi.stream_of(h)
+    plane = B * Ch * HW * 4
+    report("gru_gate_zr 184x312", timeit(lambda: L.dkt_gru_gate_zr(
+        azr.data_ptr(), cz.data_ptr(), cz.stride(0), cr.data_ptr(), cr.stride(0), h.data_ptr(), h.stride(0),
+        z.data_ptr(), rh.data_ptr(), rh.stride(0), B, Ch, HW, 0, st), n=100), bytes_=7 * plane)
+    report("gru_gate_out 184x312", timeit(lambda: L.dkt_gru_gate_out(
+        aq.data_ptr(), cq.data_ptr(), cq.stride(0), z.data_ptr(), h.data_ptr(), h.stride(0),
+        out.data_ptr(), out.stride(0), B, Ch, HW, 0, st), n=100), bytes_=5 * plane)
+
+
+CONV_LAYERS = [
+    # name, src channels, Cout, H, W, k, relu
+    ("gru08.zr 384->256 @184x312", [128, 128, 128], 256, 184, 312, 3, False),
+    ("gru08.q  384->128 @184x312", [128, 128, 128], 128, 184, 312, 3, False),
+    ("gru16.zr 384->256 @92x156", [128, 128, 128], 256, 92, 156, 3, False),
+    ("gru32.zr 256->256 @46x78", [128, 128], 256, 46, 78, 3, False),
+    ("enc.convc1 36->64 1x1", [36], 64, 184, 312, 1, True),
+    ("enc.convc2 64->64", [64], 64, 184, 312, 3, True),
+    ("enc.conv 128->126", [64, 64], 126, 184, 312, 3, True),
+    ("flow_head.conv1 128->256", [128], 256, 184, 312, 3, True),
+    ("flow_head.conv2 256->2", [256], 2, 184, 312, 3, False),
+    ("mask.2 256->144 1x1", [256], 144, 184, 312, 1, False),
+]
+
+
+@torch.no_grad()
+def bench_conv():
+    from dkt_stereo_amd import conv
+    torch.backends.cudnn.benchmark = True
+    for name, chans, cout, H, W, k, relu in CONV_LAYERS:
+        cin = sum(chans)
+        layer = torch.nn.Conv2d(cin, cout, k, padding=k // 2).to(DEV)
+        xs = [torch.randn(1, c, H, W, device=DEV) for c in chans]
+        xcat = torch.cat(xs, 1)
+        fl = 2.0 * H * W * cin * k * k * cout
+        ref = F.conv2d(xcat.double(), layer.weight.double(), layer.bias.double(), padding=k // 2)
+        if relu:
+            ref = ref.clamp_min(0)
+        for be in ("miopen", "f16x3", "f16x2", "f16"):
+            conv.set_backend(be)
+            arg = xcat if be == "miopen" else (xs if len(xs) > 1 else xs[0])
+            us = timeit(lambda: conv.conv2d(arg, layer, relu=relu), n=20, warm=3)
+            err = float((conv.conv2d(arg, layer, relu=relu).double() - ref).abs().max() / ref.abs().max())
+            report("conv %-30s %-6s" % (name, be), us, flops=fl)
+            RESULTS["conv %-30s %-6s" % (name, be)]["rel_err"] = err
+            print("     rel err %.2e" % err)
+        conv.set_backend("miopen")
+
+
+def _model(backend="miopen"):
+    from dkt_stereo_amd import conv
+    from dkt_stereo_amd.raft_stereo import RAFTStereo
+    conv.set_backend(backend)
+    m = RAFTStereo()
+    sd = _synth.torch_state_dict(_synth.shapes_of(m), 7)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+@torch.no_grad()
+def bench_e2e():
+    from dkt_stereo_amd import conv
+    torch.backends.cudnn.benchmark = True
+    i1, i2 = _synth.image_pair(1000, 1, 736, 1248, 12)
+    i1, i2 = G(i1), G(i2)
+    base = None
+    for be in ("miopen", "f16x3", "f16x2", "f16"):
+        m = _model(be)
+        for _ in range(2):
+            _, up = m(i1, i2, iters=32, test_mode=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            _, up = m(i1, i2, iters=32, test_mode=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        fm = m.encode(i1, i2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.iterate(*fm, 32)
+        torch.cuda.synchronize()
+        hot = (time.perf_counter() - t0) * 1e3
+        if base is None:
+            base = up.clone()
+        d = float((up - base).abs().max())
+        epe = float((up - base).abs().mean())
+        print("e2e 736x1248 32 iters  %-7s %8.2f ms/pair (%.2f pairs/s)  hot path %.2f ms  "
+              "max|d vs miopen| %.3e  mean %.3e" % (be, ms, 1e3 / ms, hot, d, epe), flush=True)
+        RESULTS["e2e " + be] = {"ms_per_pair": ms, "hot_ms": hot, "max_abs_vs_miopen": d, "mean_abs_vs_miopen": epe}
+    conv.set_backend("miopen")
+
+
+@torch.no_grad()
+def bench_autocast():
+    """Vendor convolutions under torch autocast (what the reference's mixed_precision
+    flag does, raft_stereo.py:156): speed and drift of the update block in half precision."""
+    i1, i2 = _synth.image_pair(1000, 1, 736, 1248, 12)
+    i1, i2 = G(i1), G(i2)
+    m = _model("miopen")
+    fm = m.encode(i1, i2)
+    _, base = m.iterate(*fm, 32)
+    for dt in (torch.float16, torch.bfloat16):
+        try:
+            with torch.autocast("cuda", dtype=dt):
+                for _ in range(2):
+                    _, up = m.iterate(*fm, 32)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, up = m.iterate(*fm, 32)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3
+            print("autocast %s: hot path %.2f ms, max|d| %.3e mean %.3e" % (
+                dt, ms, float((up.float() - base).abs().max()), float((up.float() - base).abs().mean())), flush=True)
+        except Exception as e:  # noqa: BLE001
+            print("autocast %s failed: %s" % (dt, str(e)[:200]))
+
+
+@torch.no_grad()
+def bench_volumes():
+    from dkt_stereo_amd.geometry import Combined_Geo_Encoding_Volume
+    from dkt_stereo_amd.submodule import build_concat_volume, build_gwc_volume
+    a, b = (torch.randn(1, 96, 184, 312, device=DEV) for _ in range(2))
+    report("gwc_volume IGEV 96ch G=8 D=48", timeit(lambda: build_gwc_volume(a, b, 48, 8), n=20),
+           bytes_=2 * a.numel() * 4 + 8 * 48 * 184 * 312 * 4)
+    a, b = (torch.randn(1, 320, 136, 240, device=DEV) for _ in range(2))
+    report("gwc_volume GwcNet 320ch G=40 D=48", timeit(lambda: build_gwc_volume(a, b, 48, 40), n=20),
+           bytes_=2 * a.numel() * 4 + 40 * 48 * 136 * 240 * 4)
+    a, b = (torch.randn(1, 12, 136, 240, device=DEV) for _ in range(2))
+    report("concat_volume GwcNet 12ch D=48", timeit(lambda: build_concat_volume(a, b, 48), n=20),
+           bytes_=2 * a.numel() * 4 + 24 * 48 * 136 * 240 * 4)
+    m1, m2 = (torch.randn(1, 96, 184, 312, device=DEV) for _ in range(2))
+    geo = torch.randn(1, 8, 48, 184, 312, device=DEV)
+    fn = Combined_Geo_Encoding_Volume(m1, m2, geo, num_levels=2, radius=4)
+    disp = torch.rand(1, 1, 184, 312, device=DEV) * 40
+    coords = torch.arange(312, device=DEV).float().view(1, 1, 312, 1).repeat(1, 184, 1, 1)
+    report("geo_lookup IGEV cfg3", timeit(lambda: fn(disp, coords), n=50), bytes_=184 * 312 * 1376)
+
+
+def main():
+    which = sys.argv[1:] or ["lookup", "build", "gates", "conv", "e2e", "autocast", "volumes"]
+    fns = dict(lookup=bench_lookup, build=bench_build, gates=bench_gates, conv=bench_conv, e2e=bench_e2e,
+               autocast=bench_autocast, volumes=bench_volumes)
+    for w in which:
+        print("== %s ==" % w, flush=True)
+        try:
+            fns[w]()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            print("!! %s failed: %s" % (w, e))
+    out = os.path.join(ROOT, "gpurun_out", "bench_kernels.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(RESULTS, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
