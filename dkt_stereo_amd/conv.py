@@ -87,6 +87,15 @@ def _packed_weights(layer, src_channels):
     return p
 
 
+def clear_weight_cache(module):
+    """Drops the packed fp16 weight images below `module` (needed only after writes
+    that bypass the Parameter's version counter, e.g. ``weight.data.mul_()``)."""
+    for m in module.modules():
+        m.__dict__.pop("_dkt_packed", None)
+        if hasattr(m, "_zr_key"):
+            m._zr_key = None
+
+
 def _dense(t):
     hw = t.shape[2] * t.shape[3]
     return t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == hw

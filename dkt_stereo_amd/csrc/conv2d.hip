@@ -5,29 +5,33 @@
 // 157 TFLOP/s on MI355X, 1/16 of the fp16 rate, so this kernel evaluates the
 // fp32 convolution on the fp16 matrix cores with SPLIT operands:
 //     w*s = w_hi + w_lo,  x = x_hi + x_lo   (each part fp16, s a power of two)
-//     w*x*s ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi      (fp32 accumulation)
+//     w*x*s ~= w_hi*x_hi + w_lo*x_hi + w_hi*x_lo      (fp32 accumulation)
 // which keeps ~22 significant bits per operand (fp32 has 24) at three
 // v_mfma_f32_32x32x16_f16 per product block: 833 TFLOP/s-equivalent peak, 5.3x
-// the fp32 pipe.  PASSES = 3 is that form; PASSES = 2 drops w_hi*x_lo (activations
-// rounded to fp16, weights still split); PASSES = 1 is plain fp16.  Each mode
-// is reported with its own measured deviation; the MIOpen fp32 path stays
-// available as the bit-for-bit-class parity path.
+// the fp32 pipe.  PASSES = 3 is that form (measured 1.5e-6 relative to an fp64
+// convolution, the vendor fp32 path measures 0.9e-6); PASSES = 2 drops
+// w_hi*x_lo (activations rounded to fp16, weights still split); PASSES = 1 is
+// plain fp16.
 //
 // GEMM view   D[co][px] = sum_{tap, ci} Wp[tap][ci][co] * X[ci][px + off(tap)]
 //   A = weights, pre-packed once per layer to [tap][ci/16][co][16] fp16 so a
 //       fragment (lane l: A[co = l&31][k = 8*(l>>5)..+7]) is one coalesced
-//       16-byte load per lane straight from L2 -- no LDS for weights;
+//       16-byte load per lane straight from L2 -- no LDS for weights; loads run
+//       two (tap, k16) steps ahead of the MFMAs that consume them;
 //   B = activations: NCHW fp32 in HBM (possibly several tensors = the
 //       reference's torch.cat operands, read in place), staged per 32-channel
 //       chunk as a (rows+halo) x (32+halo) pixel patch in LDS, converted to
 //       fp16 hi/lo and transposed to [pixel][channel] (pitch 80 B: conflict-
 //       free ds_read_b128 for the fragment lane l: B[k = 8*(l>>5)..+7][px = l&31]);
-//       each staged patch is reused by all taps and all output channels;
+//       each staged patch is reused by all taps and ALL output channels of the
+//       block (a block spans up to 256 output channels, so a patch is staged once);
 //   D accumulators keep pixels along lanes (C/D map col = l&31), so output
 //       stores are 128-byte NCHW rows.
-// Block = 4 waves; wave tile 64 co x (2 rows x 32 cols); WM x WN waves along
-// (co, rows).  LDS is double buffered: the fp32 loads of chunk c+1 are in flight
-// under the MFMAs of chunk c; one barrier per chunk.
+// Block = 4 waves, one per SIMD (the kernel wants the whole register file: up to
+// 128 accumulators + three weight-fragment sets in flight).  Wave tile = 64 output
+// channels x NF rows x 32 columns; WM x WN waves along (channels, rows).  LDS is
+// double buffered: the fp32 loads of chunk c+1 are in flight under the MFMAs of
+// chunk c; one barrier per chunk.
 #include "dkt_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -57,10 +61,10 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
     return v.u;
 }
 
-template <int KS, int WM, int WN, int PASSES>
-__global__ __launch_bounds__(256, WM == 2 ? 2 : 1) void conv2d_f16s_kernel(ConvArgs a) {
+template <int KS, int WM, int WN, int NF, int PASSES>
+__global__ __launch_bounds__(256, 1) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int HALO = KS / 2;
-    constexpr int TR = 2 * WN;               // output rows per block
+    constexpr int TR = NF * WN;              // output rows per block
     constexpr int PR = TR + 2 * HALO;        // patch rows
     constexpr int PC = 32 + 2 * HALO;        // patch cols
     constexpr int NPP = PR * PC;             // patch pixels
@@ -70,6 +74,8 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 1) void conv2d_f16s_kernel(ConvA
     constexpr int STAGE = PLANE * NPLANES;
     constexpr int NITEMS = NPP * 16;         // (pixel, channel pair) items per chunk
     constexpr int IT = (NITEMS + 255) / 256;
+    constexpr int NSTEP = KS * KS * 2;       // (tap, 16-channel half) steps per chunk
+    constexpr int AR = (NSTEP % 3 == 0) ? 3 : 2;   // weight-fragment ring (prefetch distance AR-1)
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 2 * STAGE words
 
     const int tid = threadIdx.x;
@@ -82,20 +88,9 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 1) void conv2d_f16s_kernel(ConvA
     const int b = blockIdx.z;
     const long HW = (long)a.H * a.W;
 
-    // ---- per-thread staging plan (independent of the channel chunk) ----
-    int s_off[IT];        // offset inside a channel plane, or -1 when outside the image / unused
-    int s_lds[IT];        // LDS word index = pixel*PITCH + channel pair
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int item = tid + 256 * it;
-        const int cp = item / NPP, pp = item - cp * NPP;
-        const int pr = pp / PC, pc = pp - pr * PC;
-        const int ih = h0 - HALO + pr, iw = w0 - HALO + pc;
-        const bool ok = item < NITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        s_off[it] = ok ? ih * a.W + iw : -1;
-        s_lds[it] = item < NITEMS ? pp * PITCH + cp : -1;
-    }
-
+    // ---- staging: item = (patch pixel pp, channel pair cp), item = tid + 256*it.
+    // The (pp, cp) -> address arithmetic is recomputed per chunk (a few VALU ops per
+    // item against ~14k MFMA cycles per chunk) rather than held in 2*IT registers.
     float2 sreg[IT];
     auto stage_load = [&](int chunk) {
         // which source tensor holds this 32-channel chunk (wave-uniform scan)
@@ -106,11 +101,17 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 1) void conv2d_f16s_kernel(ConvA
         }
         const float *base = a.src[s] + (long)b * a.src_bs[s] + (long)c0 * HW;
         const int nch = a.src_ch[s] - c0;   // valid channels from c0 on (may exceed 32)
+        int t = tid;
+        asm volatile("" : "+v"(t));          // opaque: stops the plan being hoisted into 2*IT live registers
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int ch = 2 * ((tid + 256 * it) / NPP);      // channel pair of this item
-            const bool ok = s_off[it] >= 0;
-            const long o = (long)ch * HW + (ok ? s_off[it] : 0);
+            const int item = t + 256 * it;
+            const int cp = item / NPP, pp = item - cp * NPP;
+            const int pr = pp / PC, pc = pp - pr * PC;
+            const int ih = h0 - HALO + pr, iw = w0 - HALO + pc;
+            const bool ok = item < NITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            const int ch = 2 * cp;
+            const long o = (long)ch * HW + (ok ? ih * a.W + iw : 0);
             float x0 = 0.0f, x1 = 0.0f;
             if (ok && ch < nch) x0 = base[o];
             if (ok && ch + 1 < nch) x1 = base[o + HW];
@@ -118,77 +119,107 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 1) void conv2d_f16s_kernel(ConvA
         }
     };
     auto stage_store = [&](unsigned *buf) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            if (s_lds[it] < 0) continue;
+            const int item = t + 256 * it;
+            if (item >= NITEMS) continue;
+            const int cp = item / NPP, pp = item - cp * NPP;
+            const int w = pp * PITCH + cp;
             float x0 = fminf(fmaxf(sreg[it].x, -65504.0f), 65504.0f);
             float x1 = fminf(fmaxf(sreg[it].y, -65504.0f), 65504.0f);
             const _Float16 h0_ = (_Float16)x0, h1_ = (_Float16)x1;
-            buf[s_lds[it]] = pack_h2(h0_, h1_);
+            buf[w] = pack_h2(h0_, h1_);
             if (NPLANES == 2) {
                 const _Float16 l0 = (_Float16)(x0 - (float)h0_), l1 = (_Float16)(x1 - (float)h1_);
-                buf[PLANE + s_lds[it]] = pack_h2(l0, l1);
+                buf[PLANE + w] = pack_h2(l0, l1);
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NF];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NF; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
     const int li = lane & 31, kg = lane >> 5;
     const int co_w = co_blk + wm * 64;                 // this wave's first output channel
+    const bool wave_on = co_w < a.CoutPad;             // waves past the (64-padded) channel count idle
     // weight fragment base (halves): ((tap*nch16 + ch16)*CoutPad + co)*16 + kg*8
-    const long wlane = ((long)(co_w + li)) * 16 + kg * 8;
+    const long wlane = ((long)((wave_on ? co_w : 0) + li)) * 16 + kg * 8;
+    const long wstep = (long)a.CoutPad * 16;           // one 16-channel slab
     const int nchunks = a.nch16 / 2;
 
-    auto compute = [&](const unsigned *buf, int chunk) {
+    f16x8 Ahi[AR][2], Alo[AR][2];
+    f16x8 Bhi[2][NF], Blo[2][NF];
+    auto loadA = [&](int slot, int chunk, int step) {
+        const int tap = step >> 1, kh = step & 1;
+        const long wbase = ((long)tap * a.nch16 + (chunk * 2 + kh)) * wstep + wlane;
 #pragma unroll
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            const int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                const long wbase = ((long)tap * a.nch16 + (chunk * 2 + kh)) * a.CoutPad * 16 + wlane;
-                f16x8 ahi[2], alo[2], bhi[2], blo[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    ahi[m] = *(const f16x8 *)(a.whi + wbase + m * 32 * 16);
-                    if (PASSES >= 2) alo[m] = *(const f16x8 *)(a.wlo + wbase + m * 32 * 16);
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int pp = (wn * 2 + n + dy) * PC + li + dx;
-                    const unsigned *pb = buf + pp * PITCH + kh * 8 + kg * 4;
-                    bhi[n] = *(const f16x8 *)pb;
-                    if (NPLANES == 2) blo[n] = *(const f16x8 *)(pb + PLANE);
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], bhi[n], acc[m][n], 0, 0, 0);
-                        if (PASSES >= 2)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], bhi[n], acc[m][n], 0, 0, 0);
-                        if (PASSES == 3)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], blo[n], acc[m][n], 0, 0, 0);
-                    }
-            }
+        for (int m = 0; m < 2; ++m) {
+            Ahi[slot][m] = *(const f16x8 *)(a.whi + wbase + m * 32 * 16);
+            if (PASSES >= 2) Alo[slot][m] = *(const f16x8 *)(a.wlo + wbase + m * 32 * 16);
         }
+    };
+    auto loadB = [&](int slot, const unsigned *buf, int step) {
+        const int tap = step >> 1, kh = step & 1;
+        const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int pp = (wn * NF + n + dy) * PC + li + dx;
+            const unsigned *pb = buf + pp * PITCH + kh * 8 + kg * 4;
+            Bhi[slot][n] = *(const f16x8 *)pb;
+            if (NPLANES == 2) Blo[slot][n] = *(const f16x8 *)(pb + PLANE);
+        }
+    };
+    auto mma = [&](int as, int bs) {
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[as][m], Bhi[bs][n], acc[m][n], 0, 0, 0);
+                if (PASSES >= 2)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[as][m], Bhi[bs][n], acc[m][n], 0, 0, 0);
+                if (PASSES == 3)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[as][m], Blo[bs][n], acc[m][n], 0, 0, 0);
+            }
     };
 
     stage_load(0);
     stage_store(lds);
     __syncthreads();
+    if (wave_on) {
+#pragma unroll
+        for (int s = 0; s < AR - 1; ++s) loadA(s, 0, s);
+        loadB(0, lds, 0);
+    }
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
+        const unsigned *cur = lds + (c & 1) * STAGE;
+        unsigned *nxt = lds + ((c + 1) & 1) * STAGE;
         if (more) stage_load(c + 1);
-        compute(lds + (c & 1) * STAGE, c);
-        if (more) stage_store(lds + ((c + 1) & 1) * STAGE);
+        if (wave_on) {
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                // weights for step s+AR-1 (possibly the next chunk's first steps)
+                const int sa = s + AR - 1;
+                if (sa < NSTEP) loadA(sa % AR, c, sa);
+                else if (more) loadA(sa % AR, c + 1, sa - NSTEP);
+                if (s + 1 < NSTEP) loadB((s + 1) & 1, cur, s + 1);
+                // keep the prefetches above the MFMA block: left alone the scheduler sinks
+                // every load to just before its first use and each step eats a full L2 latency
+                __builtin_amdgcn_sched_barrier(0);
+                mma(s % AR, s & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) stage_store(nxt);
         __syncthreads();
+        if (more && wave_on) loadB(0, nxt, 0);      // NSTEP is even: step 0 always uses B slot 0
     }
 
     // ---- epilogue: un-scale, bias, optional ReLU, NCHW stores (128-byte rows) ----
@@ -196,8 +227,8 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 1) void conv2d_f16s_kernel(ConvA
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int oh = h0 + wn * 2 + n, ow = w0 + li;
+        for (int n = 0; n < NF; ++n) {
+            const int oh = h0 + wn * NF + n, ow = w0 + li;
             const bool pok = oh < a.H && ow < a.W;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -247,8 +278,8 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(PackArgs a) {
     a.wlo[i] = (_Float16)(v - (float)hi);
 }
 
-// output channels are tiled 64 per wave; layers wider than 64 use two waves (128) per block
-static int conv_cout_pad(int Cout) { return Cout <= 64 ? 64 : (Cout + 127) & ~127; }
+// output channels are owned 64 per wave; the packed image is padded to that granule
+static int conv_cout_pad(int Cout) { return (Cout + 63) & ~63; }
 
 static int conv_padded_channels(const int *src_ch, int nsrc) {
     int t = 0;
@@ -258,8 +289,7 @@ static int conv_padded_channels(const int *src_ch, int nsrc) {
 
 extern "C" long dkt_conv2d_packed_elems(const int *src_channels, int nsrc, int Cout, int KH, int KW) {
     if (!src_channels || nsrc < 1 || nsrc > CONV_MAX_SRC || Cout <= 0 || KH <= 0 || KW <= 0) return DKT_E_SHAPE;
-    const int cpad = conv_cout_pad(Cout);
-    return (long)KH * KW * (conv_padded_channels(src_channels, nsrc) / 16) * cpad * 16;
+    return (long)KH * KW * (conv_padded_channels(src_channels, nsrc) / 16) * conv_cout_pad(Cout) * 16;
 }
 
 extern "C" int dkt_conv2d_pack_weights(const float *w, const int *src_channels, int nsrc,
@@ -290,28 +320,40 @@ extern "C" int dkt_conv2d_pack_weights(const float *w, const int *src_channels, 
     return dkt_launch_status();
 }
 
-template <int KS, int WM, int WN, int PASSES>
+template <int KS, int WM, int WN, int NF, int PASSES>
 static int launch_conv(const ConvArgs &a, int B, hipStream_t st) {
     constexpr int HALO = KS / 2;
-    constexpr int NPP = (2 * WN + 2 * HALO) * (32 + 2 * HALO);
+    constexpr int NPP = (NF * WN + 2 * HALO) * (32 + 2 * HALO);
     constexpr int STAGE = NPP * 20 * (PASSES == 3 ? 2 : 1);
     const size_t lds = (size_t)2 * STAGE * sizeof(unsigned);
-    auto kern = conv2d_f16s_kernel<KS, WM, WN, PASSES>;
+    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const int tiles_h = (a.H + 2 * WN - 1) / (2 * WN);
+    const int tiles_h = (a.H + NF * WN - 1) / (NF * WN);
     dim3 grid((unsigned)(a.tiles_w * tiles_h), (unsigned)((a.Cout + 64 * WM - 1) / (64 * WM)), (unsigned)B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     return dkt_launch_status();
 }
 
+// Tile shape by layer width and image size.  Wide layers put all four waves on the
+// channel axis (one block = up to 256 channels: each patch is staged once); narrow
+// layers put them on rows.  Images too small to give every CU a block with 4-row
+// wave tiles use 2-row wave tiles.
 template <int KS, int PASSES>
 static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
-    // narrow layers (<= 64 output channels) put all four waves along the rows
-    if (a.Cout <= 64) return launch_conv<KS, 1, 4, PASSES>(a, B, st);
-    return launch_conv<KS, 2, 2, PASSES>(a, B, st);
+    const long tiles4 = (long)a.tiles_w * ((a.H + 3) / 4) * B;    // blocks if a block covers 4 rows
+    if (a.Cout <= 64) {
+        if (tiles4 / 2 >= 256) return launch_conv<KS, 1, 4, 2, PASSES>(a, B, st);   // 64 co x 8 rows
+        return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);                          // 64 co x 4 rows
+    }
+    if (a.Cout <= 128) {
+        if (tiles4 / 2 >= 256) return launch_conv<KS, 2, 2, 4, PASSES>(a, B, st);   // 128 co x 8 rows
+        return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);                          // 128 co x 4 rows
+    }
+    if (tiles4 >= 256) return launch_conv<KS, 4, 1, 4, PASSES>(a, B, st);           // 256 co x 4 rows
+    return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);                              // 256 co x 2 rows
 }
 
 extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride,

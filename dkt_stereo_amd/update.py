@@ -100,6 +100,7 @@ class ConvGRU(nn.Module):
             rh = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
             zr_in, q_in = [h, *x_list], [rh, *x_list]
         azr = conv2d(zr_in, self._merged_zr())                    # (B, 2Ch, H, W)
+        _ffi.require_gpu(azr)        # fp32 only: under torch.autocast the vendor conv returns half
         z = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
         # z = sigmoid(az+cz); r = sigmoid(ar+cr); rh <- r*h
         rc = L.dkt_gru_gate_zr(azr.data_ptr(), cz.data_ptr(), cz.stride(0), cr.data_ptr(), cr.stride(0),
@@ -107,6 +108,7 @@ class ConvGRU(nn.Module):
                                B, Ch, HW, dev, st)
         _ffi.check(rc, "dkt_gru_gate_zr")
         aq = conv2d(q_in, self.convq)
+        _ffi.require_gpu(aq)
         out = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
         # q = tanh(aq+cq); h' = (1-z)*h + z*q
         rc = L.dkt_gru_gate_out(aq.data_ptr(), cq.data_ptr(), cq.stride(0), z.data_ptr(),

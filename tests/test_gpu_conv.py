@@ -81,8 +81,10 @@ def test_conv_weight_cache_invalidation():
     layer = torch.nn.Conv2d(32, 64, 3, padding=1).to(DEV)
     x = G(_synth.normal((1, 32, 8, 40), 91, "x"))
     a = conv.conv2d(x, layer)
-    layer.weight.data.mul_(2.0)          # in-place write bumps the version counter
-    layer.bias.data.zero_()
+    # in-place writes to the Parameter (what load_state_dict / optimizers do) bump its version
+    # counter; writes through `.data` do not -- conv.clear_weight_cache() covers those
+    layer.weight.mul_(2.0)
+    layer.bias.zero_()
     b = conv.conv2d(x, layer)
     ref = F.conv2d(x.double(), layer.weight.double(), None, padding=1)
     assert float((b.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
