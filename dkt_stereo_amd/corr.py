@@ -17,9 +17,10 @@ import torch
 from . import _ffi
 
 
-def _build_pyramid(fmap1, fmap2, num_levels, divisor):
+def _build_pyramid(fmap1, fmap2, num_levels, divisor, out=None):
     """dkt_corr1d_build: all-pairs correlation + avg-pool pyramid in one launch.
-    Returns L tensors shaped like the reference's pyramid entries (N,1,1,W2_i)."""
+    Returns L tensors shaped like the reference's pyramid entries (N,1,1,W2_i);
+    `out` (a previous result of the same shape) is overwritten in place if given."""
     _ffi.require_gpu(fmap1, fmap2)
     _ffi.require_no_grad(fmap1, fmap2)
     fmap1 = fmap1.contiguous()
@@ -29,8 +30,12 @@ def _build_pyramid(fmap1, fmap2, num_levels, divisor):
     if (B, C, H) != (B2, C2, H2):
         raise ValueError("fmap1 %s and fmap2 %s disagree" % (tuple(fmap1.shape), tuple(fmap2.shape)))
     N = B * H * W1
-    pyr = [torch.empty((N, 1, 1, W2 >> i), device=fmap1.device, dtype=torch.float32)
-           for i in range(num_levels)]
+    if out is not None:
+        pyr = out
+        assert len(pyr) == num_levels and all(p.shape == (N, 1, 1, W2 >> i) for i, p in enumerate(pyr))
+    else:
+        pyr = [torch.empty((N, 1, 1, W2 >> i), device=fmap1.device, dtype=torch.float32)
+               for i in range(num_levels)]
     rc = _ffi.lib().dkt_corr1d_build(fmap1.data_ptr(), fmap2.data_ptr(), _ffi.ptr_array(pyr),
                                      B, C, H, W1, W2, num_levels, float(divisor),
                                      _ffi.device_of(fmap1), _ffi.stream_of(fmap1))
@@ -62,11 +67,18 @@ class CorrBlock1D:
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         self.num_levels = num_levels
         self.radius = radius
+        self._w2 = fmap2.shape[3]
+        self.corr_pyramid = None
+        self.rebuild(fmap1, fmap2)
+
+    def rebuild(self, fmap1, fmap2):
+        """Recomputes the pyramid for a new pair INTO the existing tensors (same shapes):
+        lets a captured HIP graph of the lookup keep its pointers."""
         C = fmap1.shape[1]
         # corr / sqrt(C) (core/corr.py:156); the kernel divides like the reference
-        self._w2 = fmap2.shape[3]
-        self.corr_pyramid = _build_pyramid(fmap1.float(), fmap2.float(), num_levels,
-                                           float(torch.sqrt(torch.tensor(C).float())))
+        self.corr_pyramid = _build_pyramid(fmap1.float(), fmap2.float(), self.num_levels,
+                                           float(torch.sqrt(torch.tensor(C).float())),
+                                           out=self.corr_pyramid)
 
     def __call__(self, coords):
         return _lookup(self.corr_pyramid, coords, self.radius, self._w2)

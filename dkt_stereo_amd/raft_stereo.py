@@ -80,11 +80,81 @@ class RAFTStereo(nn.Module):
         up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
         return up.reshape(N, D, factor * H, factor * W)
 
+    #: replay the GRU iteration from a captured HIP graph (one capture per input shape)
+    use_hip_graph = True
+
+    def _one_iteration(self, corr_fn, coords0, coords1, net_state, inp_list, need_mask):
+        """One pass of raft_stereo.py:146-167 updating coords1 / net_state IN PLACE
+        (static buffers, so the same code can be captured once and replayed)."""
+        args = self.args
+        n = args.n_gru_layers
+        corr = corr_fn(coords1)
+        flow = coords1 - coords0
+        nets = list(net_state)
+        if n == 3 and args.slow_fast_gru:
+            nets = self.update_block(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+        if n >= 2 and args.slow_fast_gru:
+            nets = self.update_block(nets, inp_list, iter32=(n == 3), iter16=True, iter08=False, update=False)
+        nets, up_mask, delta_flow = self.update_block(nets, inp_list, corr, flow, iter32=(n == 3),
+                                                      iter16=(n >= 2), need_mask=need_mask)
+        delta_flow[:, 1] = 0.0          # stereo: project onto the epipolar line
+        coords1.add_(delta_flow)
+        for dst, src in zip(net_state, nets):
+            if dst is not src:
+                dst.copy_(src)
+        return up_mask
+
+    def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init):
+        """Same arithmetic as the eager loop; iterations 2..iters-1 are replays of one
+        captured HIP graph (~60 launches per iteration leave the CPU out of the loop)."""
+        args = self.args
+        b, _, h, w = net_list[0].shape
+        key = (fmap1.device, tuple(fmap1.shape), tuple(fmap2.shape))
+        st = getattr(self, "_graph_state", None)
+        if st is None or st["key"] != key:
+            st = dict(key=key, graph=None)
+            st["corr"] = CORR_IMPLEMENTATIONS[args.corr_implementation](
+                fmap1, fmap2, radius=args.corr_radius, num_levels=args.corr_levels)
+            st["coords0"] = coords_grid(b, h, w).to(fmap1.device)
+            st["coords1"] = st["coords0"].clone()
+            st["net"] = [t.clone() for t in net_list]
+            st["inp"] = [[t.clone() for t in scale] for scale in inp_list]
+            self._graph_state = st
+        else:
+            st["corr"].rebuild(fmap1, fmap2)
+            st["coords1"].copy_(st["coords0"])
+            for dst, src in zip(st["net"], net_list):
+                dst.copy_(src)
+            for ds, ss in zip(st["inp"], inp_list):
+                for dst, src in zip(ds, ss):
+                    dst.copy_(src)
+        if flow_init is not None:
+            st["coords1"].add_(flow_init)
+        step = lambda mask: self._one_iteration(st["corr"], st["coords0"], st["coords1"],  # noqa: E731
+                                                st["net"], st["inp"], mask)
+        done = 0
+        if st["graph"] is None:
+            step(False)                      # eager once: packs weights, sizes the allocator
+            done = 1
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(False)
+            st["graph"] = g
+        for _ in range(iters - 1 - done):
+            st["graph"].replay()
+        up_mask = step(True)
+        flow = st["coords1"] - st["coords0"]
+        return flow, self.upsample_flow(flow, up_mask)[:, :1]
+
     def iterate(self, fmap1, fmap2, net_list, inp_list, iters, flow_init=None):
         """The hot path, raft_stereo.py:118-183 in test_mode: correlation build,
         then `iters` x (lookup, update block), then convex upsampling."""
         args = self.args
         n = args.n_gru_layers
+        if (self.use_hip_graph and iters >= 3 and fmap1.is_cuda and args.corr_implementation == "reg"
+                and CORR_IMPLEMENTATIONS["reg"].__name__ == "CorrBlock1D"):
+            return self._iterate_graphed(fmap1, fmap2, net_list, inp_list, iters, flow_init)
         corr_block = CORR_IMPLEMENTATIONS[args.corr_implementation]
         corr_fn = corr_block(fmap1, fmap2, radius=args.corr_radius, num_levels=args.corr_levels)
         b, _, h, w = net_list[0].shape

@@ -148,3 +148,29 @@ def test_reduced_pass_backends_report_their_deviation(backend, golden):
     epe = float(np.mean(np.abs(up[:, :, ::s, ::s].cpu().numpy() - g["256x512_it32/flow_up"])))
     print("256x512_it32 %s: max|d_up| %.3e EPE %.3e" % (backend, d, epe))
     assert d <= 0.5
+
+
+@torch.no_grad()
+def test_hip_graph_replay_matches_eager():
+    """The captured-iteration path (RAFTStereo.use_hip_graph) must give exactly the eager
+    result, on the first call (capture) and on a later call with another pair (replay only)."""
+    from test_gpu_parity import _raft, maxabs
+    model, _ = _raft()
+    outs = {}
+    for mode in (False, True):
+        model.use_hip_graph = mode
+        model._graph_state = None
+        for seed, shift in ((0, 12), (5, 30)):
+            i1, i2 = _synth.image_pair(seed, 1, 128, 256, shift)
+            lo, up = model(G(i1), G(i2), iters=7, test_mode=True)
+            outs[(mode, seed)] = (lo.clone(), up.clone())
+    for seed in (0, 5):
+        assert maxabs(outs[(True, seed)][0], outs[(False, seed)][0]) <= 1e-6
+        assert maxabs(outs[(True, seed)][1], outs[(False, seed)][1]) <= 1e-6
+    # a different input shape triggers a fresh capture
+    i1, i2 = _synth.image_pair(1, 1, 64, 128, 12)
+    model.use_hip_graph = True
+    _, a = model(G(i1), G(i2), iters=5, test_mode=True)
+    model.use_hip_graph = False
+    _, b = model(G(i1), G(i2), iters=5, test_mode=True)
+    assert maxabs(a, b) <= 1e-6

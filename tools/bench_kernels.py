@@ -162,6 +162,22 @@ def bench_conv():
         conv.set_backend("miopen")
 
 
+@torch.no_grad()
+def bench_ablate():
+    """Timing-only ablations of the flagship conv shape (gru08 z|r): which part costs what."""
+    from dkt_stereo_amd import conv
+    conv.set_backend("f16x3")
+    layer = torch.nn.Conv2d(384, 256, 3, padding=1).to(DEV)
+    xs = [torch.randn(1, 128, 184, 312, device=DEV) for _ in range(3)]
+    names = {0: "full", 1: "no weight loads", 2: "no LDS fragment reads", 4: "no staging",
+             8: "no MFMA", 7: "MFMA only (no loads/staging)"}
+    for abl, nm in names.items():
+        os.environ["DKT_CONV_ABLATE"] = str(abl)
+        report("ablate zr conv: %s" % nm, timeit(lambda: conv.conv2d(xs, layer), n=20, warm=3))
+    os.environ.pop("DKT_CONV_ABLATE", None)
+    conv.set_backend("miopen")
+
+
 def _model(backend="miopen"):
     from dkt_stereo_amd import conv
     from dkt_stereo_amd.raft_stereo import RAFTStereo
@@ -254,7 +270,7 @@ def bench_volumes():
 def main():
     which = sys.argv[1:] or ["lookup", "build", "gates", "conv", "e2e", "autocast", "volumes"]
     fns = dict(lookup=bench_lookup, build=bench_build, gates=bench_gates, conv=bench_conv, e2e=bench_e2e,
-               autocast=bench_autocast, volumes=bench_volumes)
+               autocast=bench_autocast, volumes=bench_volumes, ablate=bench_ablate)
     for w in which:
         print("== %s ==" % w, flush=True)
         try:

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Runs one hot-path kernel in isolation a few times (for rocprofv3 --pmc / --kernel-trace).
+usage: prof_conv.py [zr|q|lookup|build] [reps]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+which = sys.argv[1] if len(sys.argv) > 1 else "zr"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+from dkt_stereo_amd import conv  # noqa: E402
+from dkt_stereo_amd.corr import CorrBlock1D  # noqa: E402
+
+dev = "cuda:0"
+torch.manual_seed(0)
+with torch.no_grad():
+    if which in ("zr", "q"):
+        cout = 256 if which == "zr" else 128
+        conv.set_backend(os.environ.get("DKT_CONV", "f16x3"))
+        layer = torch.nn.Conv2d(384, cout, 3, padding=1).to(dev)
+        xs = [torch.randn(1, 128, 184, 312, device=dev) for _ in range(3)]
+        for _ in range(reps):
+            conv.conv2d(xs, layer)
+    elif which in ("lookup", "build"):
+        f1, f2 = (torch.randn(1, 256, 184, 312, device=dev) for _ in range(2))
+        blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+        coords = torch.zeros(1, 2, 184, 312, device=dev)
+        coords[:, 0] = torch.arange(312, device=dev).float().view(1, 1, 312) - 60 * torch.rand(1, 184, 312, device=dev)
+        for _ in range(reps):
+            if which == "lookup":
+                blk(coords)
+            else:
+                CorrBlock1D(f1, f2, num_levels=4, radius=4)
+    torch.cuda.synchronize()
+print("done", which)
