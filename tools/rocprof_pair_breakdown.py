@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-kernel breakdown of ONE steady-state stereo pair from a rocprofv3 kernel trace of
+bench.py: the window between two consecutive corr1d_build dispatches of the timed region
+(bench.py's warm-up contains MIOpen's find-mode benchmarking, which would otherwise swamp
+the table).  Usage: rocprof_pair_breakdown.py <kernel_trace.csv> [--pair -3]"""
+import argparse
+import collections
+import csv
+import re
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--pair", type=int, default=-3, help="index of the corr1d_build dispatch that opens the window")
+    ap.add_argument("--top", type=int, default=40)
+    a = ap.parse_args()
+    rows = list(csv.DictReader(open(a.trace)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
+    lo, hi = idx[a.pair], idx[a.pair + 1]
+    win = rows[lo:hi]
+    t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
+    agg = collections.defaultdict(lambda: [0, 0, 1 << 62, 0])
+    for r in win:
+        n = re.sub(r"^void ", "", re.sub(r"\(.*", "", r["Kernel_Name"]))
+        m = re.search(r"at::native::(?:\(anonymous namespace\)::)?(\w+)", n)
+        if m:
+            f = re.findall(r"(CUDAFunctor_\w+|launch_\w+|FillFunctor|MulFunctor|tanh_kernel\w*|copy_kernel\w*)", r["Kernel_Name"])
+            n = "at::" + m.group(1) + ("[" + ",".join(sorted(set(f))) + "]" if f else "")
+        if len(n) > 68:
+            n = re.sub(r"<.*", "<...>", n)[:68]
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        k = agg[n]
+        k[0] += 1
+        k[1] += d
+        k[2] = min(k[2], d)
+        k[3] = max(k[3], d)
+    tot = sum(v[1] for v in agg.values())
+    print("# one steady-state pair: wall %.2f ms, kernel time %.2f ms, %d dispatches" % ((t1 - t0) / 1e6, tot / 1e6, len(win)))
+    print("%-68s %6s %11s %9s %9s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+    for n, (c, d, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
+        print("%-68s %6d %11.1f %9.2f %9.2f %9.2f %6.2f" % (n, c, d / 1e3, d / c / 1e3, mn / 1e3, mx / 1e3, 100.0 * d / tot))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Condenses a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into a short
-per-kernel table: calls, total, average, min, max duration (microseconds) and
-share.  Usage: rocprof_summary.py <results.db> [--top N] [--match substr]."""
+"""Condenses a rocprofv3 kernel trace (ROCm 7.2: rocpd sqlite .db or *_kernel_trace.csv) into a
+short per-kernel table: calls, total, average, min, max duration (microseconds) and share.
+Usage: rocprof_summary.py <results.db | kernel_trace.csv> [--top N] [--match substr] [--skip-first K]"""
 import argparse
+import csv
 import re
 import sqlite3
 
@@ -14,15 +15,24 @@ def short(name, width):
     return name[:width]
 
 
+def load(path):
+    if path.endswith(".csv"):
+        rows = []
+        for r in csv.DictReader(open(path)):
+            rows.append((r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        return rows
+    c = sqlite3.connect(path)
+    return c.execute("select name, (end - start) from kernels").fetchall()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("db")
+    ap.add_argument("trace")
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--match", default=None)
     ap.add_argument("--width", type=int, default=72)
     a = ap.parse_args()
-    c = sqlite3.connect(a.db)
-    rows = c.execute("select name, (end - start) from kernels").fetchall()
+    rows = load(a.trace)
     agg = {}
     for name, dur in rows:
         k = agg.setdefault(name, [0, 0, 1 << 62, 0])
