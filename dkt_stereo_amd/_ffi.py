@@ -36,9 +36,14 @@ SIGNATURES = {
     "dkt_conv2d_pack_weights": [_vp, _ip, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_f16s": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_instance_norm_workspace": [_i, _l],
+    "dkt_instance_norm": [_vp, _vp, _vp, _i, _l, _f, _i, _i, _vp],
+    "dkt_add_relu": [_vp, _vp, _vp, _l, _i, _vp],
+    "dkt_pool2x": [_vp, _vp, _l, _i, _i, _i, _vp],
+    "dkt_interp_bilinear": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
 }
 #: entry points that do not return an int status
-RESTYPES = {"dkt_conv2d_packed_elems": ctypes.c_long}
+RESTYPES = {"dkt_conv2d_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
 
 _lib = None
 

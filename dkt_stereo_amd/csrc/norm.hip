@@ -1,0 +1,213 @@
+// norm.hip -- streaming helpers around the convolutions (HBM-bound, float4, grid-stride):
+//   dkt_instance_norm   InstanceNorm2d(affine=False) [+ ReLU], two launches
+//   dkt_add_relu        relu(a + b), the residual join of core/extractor.py:60
+//   dkt_pool2x          avg_pool2d(x, 3, stride=2, padding=1)          core/update.py:87-88
+//   dkt_interp2x        bilinear resize, align_corners=True             core/update.py:93-95
+// torch runs instance norm as collect_statistics (100 us) + transform_input (224 us) + a
+// separate ReLU (28 us) on a 235 MB activation; here it is one statistics pass (fp64
+// partial sums, several blocks per plane so that 128 planes still fill 256 CUs) and one
+// normalise(+ReLU) pass.
+#include "dkt_common.h"
+
+#define IN_SPLIT_MAX 64
+
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float *__restrict__ x,
+                                                             double *__restrict__ part, long HW, int S) {
+    const int plane = blockIdx.y, s = blockIdx.x;
+    const float *p = x + (long)plane * HW;
+    const long per = ((HW + S - 1) / S + 3) & ~3L;
+    const long lo = (long)s * per;
+    long hi = lo + per;
+    if (hi > HW) hi = HW;
+    double sum = 0.0, sq = 0.0;
+    if (((uintptr_t)p & 15) == 0 && (HW & 3) == 0) {
+        for (long i = lo + 4L * threadIdx.x; i + 3 < hi; i += 1024) {
+            const float4 v = *(const float4 *)(p + i);
+            sum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            sq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = p[i];
+            sum += v;
+            sq += (double)v * v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_down(sum, o);
+        sq += __shfl_down(sq, o);
+    }
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][w] = sum;
+        red[1][w] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long)plane * S + s) * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((long)plane * S + s) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                             const double *__restrict__ part, long HW, int S,
+                                                             float eps, int relu, int blocks_per_plane) {
+    const int plane = blockIdx.y;
+    double sum = 0.0, sq = 0.0;
+    for (int s = 0; s < S; ++s) {
+        sum += part[((long)plane * S + s) * 2];
+        sq += part[((long)plane * S + s) * 2 + 1];
+    }
+    const double mean_d = sum / (double)HW;
+    double var_d = sq / (double)HW - mean_d * mean_d;      // biased variance, as instance_norm uses
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d;
+    const float invstd = 1.0f / sqrtf((float)var_d + eps);
+    const float *p = x + (long)plane * HW;
+    float *q = y + (long)plane * HW;
+    const long stride = (long)blocks_per_plane * 1024;
+    if (((uintptr_t)p & 15) == 0 && ((uintptr_t)q & 15) == 0 && (HW & 3) == 0) {
+        for (long i = blockIdx.x * 1024L + 4L * threadIdx.x; i + 3 < HW; i += stride) {
+            float4 v = *(const float4 *)(p + i);
+            v.x = (v.x - mean) * invstd; v.y = (v.y - mean) * invstd;
+            v.z = (v.z - mean) * invstd; v.w = (v.w - mean) * invstd;
+            if (relu) {
+                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            }
+            *(float4 *)(q + i) = v;
+        }
+    } else {
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)blocks_per_plane * 256) {
+            float v = (p[i] - mean) * invstd;
+            q[i] = relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
+extern "C" long dkt_instance_norm_workspace(int planes, long HW) {
+    if (planes <= 0 || HW <= 0) return DKT_E_SHAPE;
+    return (long)planes * IN_SPLIT_MAX * 2 * (long)sizeof(double);
+}
+
+extern "C" int dkt_instance_norm(const float *x, float *y, void *workspace, int planes, long HW,
+                                 float eps, int relu, int device, void *stream) {
+    if (!x || !y || !workspace) return DKT_E_NULL;
+    if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    hipStream_t st = (hipStream_t)stream;
+    int S = (2048 + planes - 1) / planes;          // ~2048 blocks in flight
+    const long max_split = (HW + 4095) / 4096;      // at least 4096 elements per block
+    if (S > max_split) S = (int)max_split;
+    if (S > IN_SPLIT_MAX) S = IN_SPLIT_MAX;
+    if (S < 1) S = 1;
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, st,
+                       x, (double *)workspace, HW, S);
+    int rc = dkt_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(instnorm_apply_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, st,
+                       x, y, (const double *)workspace, HW, S, eps, relu ? 1 : 0, S);
+    return dkt_launch_status();
+}
+
+__global__ __launch_bounds__(256) void add_relu_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                       float *__restrict__ y, long n4, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 u = ((const float4 *)a)[i], v = ((const float4 *)b)[i];
+        float4 o;
+        o.x = fmaxf(u.x + v.x, 0.0f); o.y = fmaxf(u.y + v.y, 0.0f);
+        o.z = fmaxf(u.z + v.z, 0.0f); o.w = fmaxf(u.w + v.w, 0.0f);
+        ((float4 *)y)[i] = o;
+    }
+    for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = fmaxf(a[i] + b[i], 0.0f);
+}
+
+extern "C" int dkt_add_relu(const float *a, const float *b, float *y, long n, int device, void *stream) {
+    if (!a || !b || !y) return DKT_E_NULL;
+    if (n <= 0) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const bool al = ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0;
+    const long n4 = al ? n / 4 : 0;
+    long blocks = ((al ? n4 : n) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(add_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, y, n4, n);
+    return dkt_launch_status();
+}
+
+// avg_pool2d(x, 3, stride=2, padding=1), count_include_pad=True (divide by 9 always).
+// Sum order: rows top to bottom, columns left to right (ATen's loop order), then * (1/9)?
+// ATen divides the sum by the pool size: sum / 9.
+__global__ __launch_bounds__(256) void pool2x_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                     int H, int W, int Ho, int Wo, long planes) {
+    const long total = planes * Ho * Wo;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const long pl = i / ((long)Wo * Ho);
+        const float *p = x + pl * H * W;
+        float s = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * oy - 1 + dy;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox - 1 + dx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) s = __fadd_rn(s, p[(long)iy * W + ix]);
+            }
+        }
+        y[i] = __fdiv_rn(s, 9.0f);
+    }
+}
+
+extern "C" int dkt_pool2x(const float *x, float *y, long planes, int H, int W, int device, void *stream) {
+    if (!x || !y) return DKT_E_NULL;
+    if (planes <= 0 || H <= 0 || W <= 0) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long blocks = (planes * Ho * Wo + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       x, y, H, W, Ho, Wo, planes);
+    return dkt_launch_status();
+}
+
+// F.interpolate(x, (Ho,Wo), mode='bilinear', align_corners=True): ATen's
+//   src = dst * (in-1)/(out-1);  i0 = (int)src;  l1 = src - i0;  l0 = 1 - l1
+//   out = l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
+__global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                     int H, int W, int Ho, int Wo, float sy, float sx, long planes) {
+    const long total = planes * Ho * Wo;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const long pl = i / ((long)Wo * Ho);
+        const float *p = x + pl * H * W;
+        const float fy = __fmul_rn(sy, (float)oy), fx = __fmul_rn(sx, (float)ox);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly1 = __fsub_rn(fy, (float)y0), lx1 = __fsub_rn(fx, (float)x0);
+        const float ly0 = __fsub_rn(1.0f, ly1), lx0 = __fsub_rn(1.0f, lx1);
+        const float v00 = p[(long)y0 * W + x0], v01 = p[(long)y0 * W + x1];
+        const float v10 = p[(long)y1 * W + x0], v11 = p[(long)y1 * W + x1];
+        const float top = __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01));
+        const float bot = __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11));
+        y[i] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+    }
+}
+
+extern "C" int dkt_interp_bilinear(const float *x, float *y, long planes, int H, int W, int Ho, int Wo,
+                                   int device, void *stream) {
+    if (!x || !y) return DKT_E_NULL;
+    if (planes <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.0f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.0f;
+    long blocks = (planes * Ho * Wo + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(interp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       x, y, H, W, Ho, Wo, sy, sx, planes);
+    return dkt_launch_status();
+}

@@ -11,6 +11,53 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _ffi
+from .conv import conv2d
+
+
+def _hip_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+def norm_act(norm, x, relu):
+    """norm(x) [+ ReLU].  InstanceNorm2d (affine-free, instance statistics: fnet) runs as the
+    fused dkt_instance_norm; every other norm is torch (+ F.relu)."""
+    if (isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats and _hip_ok(x)):
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        L = _ffi.lib()
+        ws = torch.empty(L.dkt_instance_norm_workspace(n * c, h * w), device=x.device, dtype=torch.uint8)
+        y = torch.empty_like(x)
+        rc = L.dkt_instance_norm(x.data_ptr(), y.data_ptr(), ws.data_ptr(), n * c, h * w, float(norm.eps),
+                                 int(relu), _ffi.device_of(x), _ffi.stream_of(x))
+        _ffi.check(rc, "dkt_instance_norm")
+        return y
+    y = norm(x)
+    return F.relu(y) if relu else y
+
+
+def add_relu(a, b):
+    """relu(a + b), one pass (dkt_add_relu)."""
+    if _hip_ok(a) and _hip_ok(b) and a.shape == b.shape and a.is_contiguous() and b.is_contiguous():
+        y = torch.empty_like(a)
+        rc = _ffi.lib().dkt_add_relu(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(),
+                                     _ffi.device_of(a), _ffi.stream_of(a))
+        _ffi.check(rc, "dkt_add_relu")
+        return y
+    return F.relu(a + b)
+
+
+class _Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, same state-dict keys) whose stride-1 1x1 / 3x3 inference
+    calls go through dkt_stereo_amd.conv.conv2d, i.e. the split-fp16 MFMA kernel that the
+    update block uses; everything else (stride 2, 7x7 stem, autograd, CPU) is plain torch."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and self.stride == (1, 1) and self.dilation == (1, 1)
+                and self.groups == 1 and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
+            return conv2d(x, self)
+        return super().forward(x)
+
 
 def _make_norm(kind, channels, groups=None):
     if kind == 'group':
@@ -27,22 +74,22 @@ def _make_norm(kind, channels, groups=None):
 class ResidualBlock(nn.Module):
     def __init__(self, in_planes, planes, norm_fn='group', stride=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.conv1 = _Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = _Conv2d(planes, planes, kernel_size=3, padding=1)
         self.norm1 = _make_norm(norm_fn, planes)
         self.norm2 = _make_norm(norm_fn, planes)
         self.downsample = None
         if stride != 1 or in_planes != planes:
             # the projection's norm is registered under both names, as upstream does
             self.norm3 = _make_norm(norm_fn, planes)
-            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+            self.downsample = nn.Sequential(_Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        y = F.relu(self.norm1(self.conv1(x)))
-        y = F.relu(self.norm2(self.conv2(y)))
+        y = norm_act(self.norm1, self.conv1(x), True)
+        y = norm_act(self.norm2, self.conv2(y), True)
         if self.downsample is not None:
-            x = self.downsample(x)
-        return F.relu(x + y)
+            x = norm_act(self.norm3, self.downsample[0](x), False)
+        return add_relu(x, y)
 
 
 def _stage(in_planes, planes, norm_fn, stride):
@@ -69,14 +116,14 @@ class _Trunk(nn.Module):
         self.norm_fn = norm_fn
         self.downsample = downsample
         self.norm1 = _make_norm(norm_fn, 64, groups=8)
-        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1 + (downsample > 2), padding=3)
+        self.conv1 = _Conv2d(3, 64, kernel_size=7, stride=1 + (downsample > 2), padding=3)
         self.relu1 = nn.ReLU(inplace=True)
         self.layer1 = _stage(64, 64, norm_fn, 1)
         self.layer2 = _stage(64, 96, norm_fn, 1 + (downsample > 1))
         self.layer3 = _stage(96, 128, norm_fn, 1 + (downsample > 0))
 
     def _trunk(self, x):
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = norm_act(self.norm1, self.conv1(x), True)
         return self.layer3(self.layer2(self.layer1(x)))
 
 
@@ -84,7 +131,7 @@ class BasicEncoder(_Trunk):
     def __init__(self, output_dim=128, norm_fn='batch', dropout=0.0, downsample=3):
         super().__init__()
         self._build_trunk(norm_fn, downsample)
-        self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        self.conv2 = _Conv2d(128, output_dim, kernel_size=1)
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init_like_reference(self)
 
@@ -108,12 +155,12 @@ class MultiBasicEncoder(_Trunk):
         self.layer4 = _stage(128, 128, norm_fn, 2)
         self.layer5 = _stage(128, 128, norm_fn, 2)
         self.outputs08 = nn.ModuleList([
-            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), nn.Conv2d(128, dim[2], 3, padding=1))
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), _Conv2d(128, dim[2], 3, padding=1))
             for dim in output_dim])
         self.outputs16 = nn.ModuleList([
-            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), nn.Conv2d(128, dim[1], 3, padding=1))
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), _Conv2d(128, dim[1], 3, padding=1))
             for dim in output_dim])
-        self.outputs32 = nn.ModuleList([nn.Conv2d(128, dim[0], 3, padding=1) for dim in output_dim])
+        self.outputs32 = nn.ModuleList([_Conv2d(128, dim[0], 3, padding=1) for dim in output_dim])
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init_like_reference(self)
 

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
 from .extractor import BasicEncoder, MultiBasicEncoder
 from .update import BasicMultiUpdateBlock
@@ -67,7 +68,7 @@ class RAFTStereo(nn.Module):
         fmap1, fmap2 = self.fnet([image1, image2])
         net_list = [torch.tanh(x[0]) for x in cnet_list]
         inp_list = [torch.relu(x[1]) for x in cnet_list]
-        inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+        inp_list = [list(conv2d(i, conv).split(split_size=conv.out_channels // 3, dim=1))
                     for i, conv in zip(inp_list, self.context_zqr_convs)]
         return fmap1.float(), fmap2.float(), net_list, inp_list
 

@@ -153,13 +153,28 @@ class BasicMotionEncoderIGEV(BasicMotionEncoder):
 
 
 def pool2x(x):
-    """core/update.py:87-88."""
-    return F.avg_pool2d(x, 3, stride=2, padding=1)
+    """core/update.py:87-88: F.avg_pool2d(x, 3, stride=2, padding=1) (dkt_pool2x)."""
+    _ffi.require_gpu(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    rc = _ffi.lib().dkt_pool2x(x.data_ptr(), y.data_ptr(), B * C, H, W, _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_pool2x")
+    return y
 
 
 def interp(x, dest):
-    """core/update.py:93-95."""
-    return F.interpolate(x, dest.shape[2:], mode='bilinear', align_corners=True)
+    """core/update.py:93-95: F.interpolate(x, dest.shape[2:], mode='bilinear',
+    align_corners=True) (dkt_interp_bilinear)."""
+    _ffi.require_gpu(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    Ho, Wo = dest.shape[2:]
+    y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    rc = _ffi.lib().dkt_interp_bilinear(x.data_ptr(), y.data_ptr(), B * C, H, W, Ho, Wo,
+                                        _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_interp_bilinear")
+    return y
 
 
 class BasicMultiUpdateBlock(nn.Module):

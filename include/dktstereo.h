@@ -176,6 +176,24 @@ int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long
                     float *out, long out_bstride, int B, int H, int W, int Cout, int KH, int KW,
                     int relu, int passes, int device, void *stream);
 
+/* ---- streaming helpers around the convolutions ---------------------------------------- */
+
+/* pool2x / interp of the update block (core/update.py:87-95): avg_pool2d(x, 3, stride=2,
+ * padding=1) and F.interpolate(x, (Ho,Wo), mode="bilinear", align_corners=True) on
+ * `planes` = B*C contiguous H x W planes. */
+int dkt_pool2x(const float *x, float *y, long planes, int H, int W, int device, void *stream);
+int dkt_interp_bilinear(const float *x, float *y, long planes, int H, int W, int Ho, int Wo,
+                        int device, void *stream);
+
+/* Encoder glue (core/extractor.py:47-60,176-178; not on the scoped hot path, but inside the
+ * timed forward): InstanceNorm2d(affine=False) with optional fused ReLU over `planes` = N*C
+ * planes of HW elements (workspace: dkt_instance_norm_workspace() bytes, device memory), and
+ * the residual join relu(a + b). */
+long dkt_instance_norm_workspace(int planes, long HW);
+int dkt_instance_norm(const float *x, float *y, void *workspace, int planes, long HW,
+                      float eps, int relu, int device, void *stream);
+int dkt_add_relu(const float *a, const float *b, float *y, long n, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

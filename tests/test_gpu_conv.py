@@ -174,3 +174,33 @@ def test_hip_graph_replay_matches_eager():
     model.use_hip_graph = False
     _, b = model(G(i1), G(i2), iters=5, test_mode=True)
     assert maxabs(a, b) <= 1e-6
+
+
+@torch.no_grad()
+def test_streaming_helpers_vs_torch():
+    """dkt_pool2x / dkt_interp_bilinear (core/update.py:87-95) and the encoder glue
+    (instance norm [+ReLU], add+ReLU) against the torch ops they replace."""
+    from dkt_stereo_amd.extractor import add_relu, norm_act
+    from dkt_stereo_amd.update import interp, pool2x
+    for (B, C, H, W) in ((1, 128, 184, 312), (2, 5, 7, 9), (1, 3, 46, 78), (1, 2, 5, 6)):
+        x = G(_synth.normal((B, C, H, W), 92, "x%d" % H))
+        want = F.avg_pool2d(x, 3, stride=2, padding=1)
+        got = pool2x(x)
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-6
+        dest = torch.empty(B, C, 2 * H, 2 * W, device=DEV)
+        want = F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
+        got = interp(x, dest)
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-6
+        odd = torch.empty(B, C, 2 * H + 1, 2 * W - 1, device=DEV)
+        assert float((interp(x, odd) - F.interpolate(x, odd.shape[2:], mode="bilinear", align_corners=True)).abs().max()) <= 2e-6
+    inorm = torch.nn.InstanceNorm2d(8)
+    for (B, C, H, W) in ((2, 8, 33, 47), (1, 8, 64, 128), (1, 8, 3, 5)):
+        x = G(_synth.normal((B, C, H, W), 93, "in%d" % H, scale=3.0)) + 1.5
+        for relu in (False, True):
+            want = inorm(x.double()).float()
+            want = want.clamp_min(0) if relu else want
+            assert float((norm_act(inorm, x, relu) - want).abs().max()) <= 5e-6
+    a, b = (G(_synth.normal((2, 7, 9, 11), 94, n)) for n in ("a", "b"))
+    assert torch.equal(add_relu(a, b), F.relu(a + b))
+    bn = torch.nn.BatchNorm2d(7).to(DEV).eval()       # every other norm stays on torch
+    assert torch.equal(norm_act(bn, a, True), F.relu(bn(a)))
