@@ -153,27 +153,21 @@ def test_reduced_pass_backends_report_their_deviation(backend, golden):
 @torch.no_grad()
 def test_hip_graph_replay_matches_eager():
     """The captured-iteration path (RAFTStereo.use_hip_graph) must give exactly the eager
-    result, on the first call (capture) and on a later call with another pair (replay only)."""
-    from test_gpu_parity import _raft, maxabs
+    result on identical encoder outputs: on the first call (capture), on a later call with
+    another pair (replay only) and after a shape change (fresh capture).  (The encoders are
+    run once per pair and shared: vendor convolutions may pick another algorithm per call.)"""
+    from test_gpu_parity import _raft
     model, _ = _raft()
-    outs = {}
-    for mode in (False, True):
-        model.use_hip_graph = mode
-        model._graph_state = None
-        for seed, shift in ((0, 12), (5, 30)):
-            i1, i2 = _synth.image_pair(seed, 1, 128, 256, shift)
-            lo, up = model(G(i1), G(i2), iters=7, test_mode=True)
-            outs[(mode, seed)] = (lo.clone(), up.clone())
-    for seed in (0, 5):
-        assert maxabs(outs[(True, seed)][0], outs[(False, seed)][0]) <= 1e-6
-        assert maxabs(outs[(True, seed)][1], outs[(False, seed)][1]) <= 1e-6
-    # a different input shape triggers a fresh capture
-    i1, i2 = _synth.image_pair(1, 1, 64, 128, 12)
-    model.use_hip_graph = True
-    _, a = model(G(i1), G(i2), iters=5, test_mode=True)
-    model.use_hip_graph = False
-    _, b = model(G(i1), G(i2), iters=5, test_mode=True)
-    assert maxabs(a, b) <= 1e-6
+    model._graph_state = None
+    for (h, w, iters, seed, shift) in ((128, 256, 7, 0, 12), (128, 256, 7, 5, 30), (64, 128, 5, 1, 12)):
+        i1, i2 = _synth.image_pair(seed, 1, h, w, shift)
+        fmap1, fmap2, net, inp = model.encode(G(i1), G(i2))
+        model.use_hip_graph = False
+        lo_e, up_e = model.iterate(fmap1, fmap2, [t.clone() for t in net], inp, iters)
+        model.use_hip_graph = True
+        lo_g, up_g = model.iterate(fmap1, fmap2, [t.clone() for t in net], inp, iters)
+        assert torch.equal(lo_g, lo_e) and torch.equal(up_g, up_e), (h, w, seed)
+    assert model._graph_state is not None and model._graph_state["graph"] is not None
 
 
 @torch.no_grad()
