@@ -15,9 +15,10 @@ data-path collective); the final disparity maps are gathered to rank 0 over
 RCCL inside the timed region, as a real sharded evaluation would.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the corr-lookup kernel (the kernel BASELINE.json's north_star sets
-                the HBM target for): algorithmic bytes per launch / its average
-                launch duration measured live with HIP events on the launch stream
+  roofline      the dominant kernel (update-block convolution, MFMA-bound): flops per
+                launch / its average launch duration measured live with HIP events on
+                the launch stream; roofline_lookup: the corr-lookup kernel (HBM-bound,
+                the kernel BASELINE.json's north_star sets the 60 % target for)
   cpu_baseline  oracle/torch_oracle.py (pure-PyTorch CPU port of the reference,
                 pinned to it by tests/golden) timed on this host, bounded sample
 """
@@ -36,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # dense
 
 
 def parse():
@@ -182,18 +184,48 @@ def main():
             dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         elapsed = float(elapsed.item())
 
-        # Lookup-kernel timing.  The timed steps above replay the GRU iteration from a
-        # captured HIP graph, where a single kernel cannot be bracketed by events; the
-        # same workload is therefore run once more through the eager path with an event
-        # pair around every lookup launch (same stream, same inputs, same kernel).
+        # Per-kernel timing.  The timed steps above replay the GRU iteration from a captured
+        # HIP graph, where a single kernel cannot be bracketed by events; the same workload is
+        # therefore run once more through the eager path with an event pair around every
+        # launch of (a) the dominant kernel -- the update-block convolution of the finest GRU,
+        # gru08 z|r, 384->256 3x3 -- and (b) the correlation lookup (same stream, same inputs,
+        # same kernels).  The cost of an empty event pair is measured and subtracted.
         model.use_hip_graph = False
         rs.CORR_IMPLEMENTATIONS = {k: timed_factory(v) for k, v in real_impls.items()}
         look_events.clear()
+        conv_events = []
+        import dkt_stereo_amd.update as upd
+        real_conv2d = upd.conv2d
+        zr_layer_id = [None]
+
+        def timed_conv2d(x, layer, relu=False):
+            big = isinstance(x, (list, tuple)) and layer.weight.shape[0] == 256 and x[0].shape[2] == h4 \
+                and sum(t.shape[1] for t in x) == 384
+            if not big:
+                return real_conv2d(x, layer, relu)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            y = real_conv2d(x, layer, relu)
+            eb.record()
+            conv_events.append((ea, eb))
+            return y
+
+        upd.conv2d = timed_conv2d
         step()
         torch.cuda.synchronize()
+        upd.conv2d = real_conv2d
         rs.CORR_IMPLEMENTATIONS = real_impls
         model.use_hip_graph = True
-        look_ms = [a.elapsed_time(b) for a, b in look_events]
+        empty = []
+        for _ in range(64):
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            eb.record()
+            empty.append((ea, eb))
+        torch.cuda.synchronize()
+        ev_overhead_ms = sorted(x.elapsed_time(y) for x, y in empty)[len(empty) // 2]
+        look_ms = [max(a.elapsed_time(b) - ev_overhead_ms, 1e-6) for a, b in look_events]
+        conv_ms = [max(a.elapsed_time(b) - ev_overhead_ms, 1e-6) for a, b in conv_events]
 
         # hot path alone (what the C ABI covers + the update block), encoders excluded
         fmap1, fmap2, net, inp = model.encode(i1, i2)
@@ -214,6 +246,10 @@ def main():
     look_avg_ms = sum(look_ms) / max(len(look_ms), 1)
     alg = lookup_bytes_per_launch(n_pix)
     achieved = alg / (look_avg_ms * 1e-3) / 1e9 if look_avg_ms > 0 else 0.0
+    passes = {"f16x3": 3, "f16x2": 2, "f16": 1}.get(_conv.get_backend(), 1)
+    conv_avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
+    conv_alg_flops = 2.0 * n_pix * 384 * 9 * 256
+    conv_tflops_exec = passes * conv_alg_flops / (conv_avg_ms * 1e-3) / 1e12 if conv_avg_ms > 0 else 0.0
     out = {
         "metric": "stereo pairs/sec at 736x1248 D=192, 32 iters (RAFT-Stereo test_mode forward)",
         "value": world * B * args.steps / elapsed,
@@ -234,13 +270,24 @@ def main():
                                % (args.height, args.width, h4, w4, args.iters, B),
                    "parallelism": "dp%d (independent pairs per rank, result gather only)" % world,
                    "conv_backend": conv_backend_name},
-        "roofline": {"kernel": "corr1d_lookup_kernel<4> (dkt_corr1d_lookup)", "bound": "hbm",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
-                     "launches_timed": len(look_ms),
-                     "note": "HIP events bracket each launch on its stream; event pairs add ~µs of "
-                             "marker overhead at this kernel size, see profiles/ for rocprofv3 durations"},
+        # dominant kernel (~70 % of a pair): the split-fp16 implicit-GEMM convolution.  It is
+        # MFMA-bound; `achieved` counts the fp16 MFMA flops it executes per launch
+        # (passes x 2*H*W*Cin*9*Cout; the fp32-equivalent algorithmic figure is 1/passes of it)
+        # against the dense fp16 MFMA peak.
+        "roofline": {"kernel": "conv2d_f16s_kernel (dkt_conv2d_f16s), gru08 z|r 384->256 3x3 @%dx%d" % (h4, w4),
+                     "bound": "mfma", "achieved": conv_tflops_exec, "peak": FP16_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": conv_tflops_exec / FP16_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "algorithmic_flops_per_launch_fp32_equiv": conv_alg_flops, "mfma_passes": passes,
+                     "fp32_equivalent_tflops": conv_tflops_exec / passes,
+                     "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                     "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
+                     "event_pair_overhead_us": 1e3 * ev_overhead_ms},
+        # the kernel BASELINE.json's north_star sets the HBM target for
+        "roofline_lookup": {"kernel": "corr1d_lookup4_kernel<4> (dkt_corr1d_lookup)", "bound": "hbm",
+                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
+                            "launches_timed": len(look_ms)},
     }
     if not args.skip_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, sd, dict(BASE_CONFIG), i1, i2)

@@ -102,31 +102,87 @@ def _dense(t):
     return t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == hw
 
 
-def conv2d(x, layer, relu=False):
+def hip_eligible(layer):
+    """True when `layer` runs on dkt_conv2d_f16s under the current backend."""
     kh, kw = layer.weight.shape[2:]
     pad = layer.padding
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
-    hip_ok = (_BACKEND in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2))
-    if not hip_ok:
-        return _vendor(x, layer, relu)
-    srcs = list(x) if isinstance(x, (list, tuple)) else [x]
-    if len(srcs) > 4:
-        srcs = srcs[:3] + [torch.cat(srcs[3:], dim=1)]
-    _ffi.require_gpu(*srcs)
-    _ffi.require_no_grad(*srcs)
-    srcs = [s if _dense(s) else s.contiguous() for s in srcs]
-    B, _, H, W = srcs[0].shape
-    chans = [int(s.shape[1]) for s in srcs]
-    pk = _packed_weights(layer, chans)
-    cout = layer.weight.shape[0]
-    out = torch.empty((B, cout, H, W), device=srcs[0].device, dtype=torch.float32)
-    n = len(srcs)
-    ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
-    ch = (ctypes.c_int * n)(*chans)
-    bs = (ctypes.c_long * n)(*[s.stride(0) for s in srcs])
-    rc = _ffi.lib().dkt_conv2d_f16s(ptrs, ch, bs, n, pk.hi.data_ptr(), pk.lo.data_ptr(),
-                                    None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale,
-                                    out.data_ptr(), out.stride(0), B, H, W, cout, kh, kw, int(bool(relu)),
-                                    _PASSES[_BACKEND], _ffi.device_of(out), _ffi.stream_of(out))
+    return _BACKEND in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2)
+
+
+class _Operands:
+    """The cat operands of one convolution marshalled for the C ABI (keeps them alive)."""
+
+    def __init__(self, x, layer):
+        srcs = list(x) if isinstance(x, (list, tuple)) else [x]
+        if len(srcs) > 4:
+            srcs = srcs[:3] + [torch.cat(srcs[3:], dim=1)]
+        _ffi.require_gpu(*srcs)
+        _ffi.require_no_grad(*srcs)
+        self.srcs = srcs = [s if _dense(s) else s.contiguous() for s in srcs]
+        self.B, _, self.H, self.W = srcs[0].shape
+        chans = [int(s.shape[1]) for s in srcs]
+        self.n = n = len(srcs)
+        self.pk = _packed_weights(layer, chans)
+        self.ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        self.ch = (ctypes.c_int * n)(*chans)
+        self.bs = (ctypes.c_long * n)(*[s.stride(0) for s in srcs])
+        self.kh, self.kw = layer.weight.shape[2:]
+        self.cout = layer.weight.shape[0]
+        self.bias = None if self.pk.bias is None else self.pk.bias.data_ptr()
+        self.device = srcs[0].device
+
+    def head(self):
+        return (self.ptrs, self.ch, self.bs, self.n, self.pk.hi.data_ptr(), self.pk.lo.data_ptr(),
+                self.bias, self.pk.inv_scale)
+
+
+def conv2d(x, layer, relu=False, out=None):
+    """`out`: optional (B,Cout,H,W) fp32 destination whose batch elements are dense (e.g. a
+    channel slice of a wider buffer -- replaces a torch.cat of the result)."""
+    if not hip_eligible(layer):
+        y = _vendor(x, layer, relu)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    op = _Operands(x, layer)
+    if out is None:
+        out = torch.empty((op.B, op.cout, op.H, op.W), device=op.device, dtype=torch.float32)
+    elif not _dense(out) or out.dtype != torch.float32 or tuple(out.shape) != (op.B, op.cout, op.H, op.W):
+        raise ValueError("conv2d(out=...) must be a dense-per-batch fp32 tensor of the result shape")
+    rc = _ffi.lib().dkt_conv2d_f16s(*op.head(), out.data_ptr(), out.stride(0), op.B, op.H, op.W, op.cout,
+                                    op.kh, op.kw, int(bool(relu)), _PASSES[_BACKEND],
+                                    _ffi.device_of(out), _ffi.stream_of(out))
     _ffi.check(rc, "dkt_conv2d_f16s")
+    return out
+
+
+def conv2d_gate_zr(x, zr_layer, cz, cr, h):
+    """ConvGRU first stage with the gates in the convolution epilogue:
+    returns (z, r*h) = (sigmoid(convz(x)+cz), sigmoid(convr(x)+cr)*h); `zr_layer` is the
+    merged convz|convr pair.  cz, cr, h: (B,Ch,H,W), dense per batch element."""
+    op = _Operands(x, zr_layer)
+    ch = op.cout // 2
+    z = torch.empty((op.B, ch, op.H, op.W), device=op.device, dtype=torch.float32)
+    rh = torch.empty_like(z)
+    rc = _ffi.lib().dkt_conv2d_f16s_gate_zr(*op.head(), cz.data_ptr(), cz.stride(0), cr.data_ptr(), cr.stride(0),
+                                            h.data_ptr(), h.stride(0), z.data_ptr(), z.stride(0),
+                                            rh.data_ptr(), rh.stride(0), op.B, op.H, op.W, ch, op.kh, op.kw,
+                                            _PASSES[_BACKEND], _ffi.device_of(z), _ffi.stream_of(z))
+    _ffi.check(rc, "dkt_conv2d_f16s_gate_zr")
+    return z, rh
+
+
+def conv2d_gate_out(x, q_layer, cq, z, h, out=None):
+    """ConvGRU second stage: (1-z)*h + z*tanh(convq(x)+cq), written to `out` (default: new
+    tensor; `out` may be `h` itself for an in-place state update)."""
+    op = _Operands(x, q_layer)
+    if out is None:
+        out = torch.empty((op.B, op.cout, op.H, op.W), device=op.device, dtype=torch.float32)
+    rc = _ffi.lib().dkt_conv2d_f16s_gate_out(*op.head(), cq.data_ptr(), cq.stride(0), z.data_ptr(), z.stride(0),
+                                             h.data_ptr(), h.stride(0), out.data_ptr(), out.stride(0),
+                                             op.B, op.H, op.W, op.cout, op.kh, op.kw,
+                                             _PASSES[_BACKEND], _ffi.device_of(out), _ffi.stream_of(out))
+    _ffi.check(rc, "dkt_conv2d_f16s_gate_out")
     return out

@@ -52,7 +52,22 @@ struct ConvArgs {
     long out_bs;
     int H, W, Cout, CoutPad, nch16, tiles_w;
     int relu;
+    // fused ConvGRU gate epilogues (core/update.py:27-31), epi = 0 none;
+    //   1: merged z|r convolution, Cout = 2*Ch:  co <  Ch: z  = sigmoid(v + cz)        -> out  (z)
+    //                                            co >= Ch: rh = sigmoid(v + cr) * h    -> out2 (r*h)
+    //   2: q convolution, Cout = Ch:             h' = (1 - z)*h + z*tanh(v + cq)        -> out  (may alias h)
+    int epi;
+    const float *e_c0;   // cz (epi 1) / cq (epi 2)
+    const float *e_c1;   // cr (epi 1) / z  (epi 2)
+    const float *e_h;    // h
+    long e_c0_bs, e_c1_bs, e_h_bs;
+    float *out2;
+    long out2_bs;
 };
+
+__device__ __forceinline__ float conv_sigmoid(float x) {
+    return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x)));
+}
 
 __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
     union { _Float16 h[2]; unsigned u; } v;
@@ -283,20 +298,54 @@ __global__ __launch_bounds__(256, 1) void conv2d_f16s_kernel(ConvArgs a) {
         }
     const bool all_co = co_w + 64 <= a.Cout;            // wave-uniform: no channel guard needed
     const int iHW = (int)HW;
-    float *ob = a.out + (long)b * a.out_bs + (long)co_lane * HW;
+    if (a.epi == 0) {
+        float *ob = a.out + (long)b * a.out_bs + (long)co_lane * HW;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int oh = h0 + wn * NF + n, ow = w0 + li;
+            if (oh >= a.H || ow >= a.W) continue;
+            float *op = ob + (long)oh * a.W + ow;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
+                    float v = acc[m][n][r] * a.out_scale + bv[m][r];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    if (all_co || co_lane + dco < a.Cout) op[dco * iHW] = v;
+                }
+        }
+        return;
+    }
+    // ---- fused GRU gates: same arithmetic, operation for operation, as gru_gates.hip ----
+    const int Ch = a.epi == 1 ? a.Cout / 2 : a.Cout;
+    const bool second = a.epi == 1 && co_w >= Ch;       // wave-uniform: this wave owns r channels
+    const int cg = co_lane - (second ? Ch : 0);         // channel inside the Ch-wide gate tensors
+    const float *pc = (second ? a.e_c1 : a.e_c0) + (long)b * (second ? a.e_c1_bs : a.e_c0_bs) + (long)cg * HW;
+    const float *pz = a.e_c1 + (long)b * a.e_c1_bs + (long)cg * HW;       // epi 2 only
+    const float *ph = a.e_h + (long)b * a.e_h_bs + (long)cg * HW;
+    float *po = (second ? a.out2 + (long)b * a.out2_bs : a.out + (long)b * a.out_bs) + (long)cg * HW;
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
         const int oh = h0 + wn * NF + n, ow = w0 + li;
         if (oh >= a.H || ow >= a.W) continue;
-        float *op = ob + (long)oh * a.W + ow;
+        const long px = (long)oh * a.W + ow;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
-                float v = acc[m][n][r] * a.out_scale + bv[m][r];
-                if (a.relu) v = fmaxf(v, 0.0f);
-                if (all_co || co_lane + dco < a.Cout) op[dco * iHW] = v;
+                if (!(all_co || co_lane + dco < a.Cout)) continue;
+                const long o = (long)dco * iHW + px;
+                const float v = acc[m][n][r] * a.out_scale + bv[m][r];
+                if (a.epi == 1) {
+                    const float g = conv_sigmoid(__fadd_rn(v, pc[o]));
+                    po[o] = second ? __fmul_rn(g, ph[o]) : g;
+                } else {
+                    const float q = tanhf(__fadd_rn(v, pc[o]));
+                    const float z = pz[o], h = ph[o];
+                    po[o] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, z), h), __fmul_rn(z, q));
+                }
             }
     }
 }
@@ -423,11 +472,19 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);                              // 256 co x 2 rows
 }
 
-extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride,
-                               int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                               float out_scale, float *out, long out_bstride,
-                               int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
-                               int device, void *stream) {
+struct ConvEpilogue {
+    int kind;
+    const float *c0, *c1, *h;
+    long c0_bs, c1_bs, h_bs;
+    float *out2;
+    long out2_bs;
+};
+
+static int conv2d_f16s_impl(const float *const *src, const int *src_channels, const long *src_bstride,
+                            int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                            float out_scale, float *out, long out_bstride,
+                            int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
+                            const ConvEpilogue *epi, int device, void *stream) {
     if (!src || !src_channels || !src_bstride || !w_hi || !w_lo || !out) return DKT_E_NULL;
     if (nsrc < 1 || nsrc > CONV_MAX_SRC || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || B > 65535) return DKT_E_SHAPE;
     if (KH != KW || (KH != 1 && KH != 3)) return DKT_E_UNSUPPORTED;
@@ -451,6 +508,17 @@ extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels,
     a.nch16 = conv_padded_channels(src_channels, nsrc) / 16;
     a.tiles_w = (W + 31) / 32;
     a.relu = relu ? 1 : 0;
+    a.epi = 0;
+    a.e_c0 = a.e_c1 = a.e_h = nullptr;
+    a.e_c0_bs = a.e_c1_bs = a.e_h_bs = 0;
+    a.out2 = nullptr;
+    a.out2_bs = 0;
+    if (epi) {
+        a.epi = epi->kind;
+        a.e_c0 = epi->c0; a.e_c1 = epi->c1; a.e_h = epi->h;
+        a.e_c0_bs = epi->c0_bs; a.e_c1_bs = epi->c1_bs; a.e_h_bs = epi->h_bs;
+        a.out2 = epi->out2; a.out2_bs = epi->out2_bs;
+    }
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
     if (KH == 3) {
@@ -461,4 +529,41 @@ extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels,
     if (passes == 3) return launch_conv_shape<1, 3>(a, B, st);
     if (passes == 2) return launch_conv_shape<1, 2>(a, B, st);
     return launch_conv_shape<1, 1>(a, B, st);
+}
+
+extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride,
+                               int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                               float out_scale, float *out, long out_bstride,
+                               int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
+                               int device, void *stream) {
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, out, out_bstride,
+                            B, H, W, Cout, KH, KW, relu, passes, nullptr, device, stream);
+}
+
+extern "C" int dkt_conv2d_f16s_gate_zr(const float *const *src, const int *src_channels, const long *src_bstride,
+                                       int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                                       float out_scale, const float *cz, long cz_bstride,
+                                       const float *cr, long cr_bstride, const float *h, long h_bstride,
+                                       float *z, long z_bstride, float *rh, long rh_bstride,
+                                       int B, int H, int W, int Ch, int KH, int KW, int passes,
+                                       int device, void *stream) {
+    if (!cz || !cr || !h || !z || !rh) return DKT_E_NULL;
+    if (Ch <= 0 || Ch % 64 != 0) return DKT_E_UNSUPPORTED;   // z and r channels must not share a wave
+    ConvEpilogue e = {1, cz, cr, h, cz_bstride, cr_bstride, h_bstride, rh, rh_bstride};
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, z, z_bstride,
+                            B, H, W, 2 * Ch, KH, KW, 0, passes, &e, device, stream);
+}
+
+extern "C" int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_channels, const long *src_bstride,
+                                        int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                                        float out_scale, const float *cq, long cq_bstride,
+                                        const float *z, long z_bstride, const float *h, long h_bstride,
+                                        float *hout, long hout_bstride,
+                                        int B, int H, int W, int Ch, int KH, int KW, int passes,
+                                        int device, void *stream) {
+    if (!cq || !z || !h || !hout) return DKT_E_NULL;
+    if (Ch <= 0) return DKT_E_SHAPE;
+    ConvEpilogue e = {2, cq, z, h, cq_bstride, z_bstride, h_bstride, nullptr, 0};
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, hout, hout_bstride,
+                            B, H, W, Ch, KH, KW, 0, passes, &e, device, stream);
 }

@@ -96,8 +96,12 @@ class RAFTStereo(nn.Module):
             nets = self.update_block(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)
         if n >= 2 and args.slow_fast_gru:
             nets = self.update_block(nets, inp_list, iter32=(n == 3), iter16=True, iter08=False, update=False)
-        nets, up_mask, delta_flow = self.update_block(nets, inp_list, corr, flow, iter32=(n == 3),
-                                                      iter16=(n >= 2), need_mask=need_mask)
+        self.update_block.inplace_state = True     # net_state tensors are private to this loop
+        try:
+            nets, up_mask, delta_flow = self.update_block(nets, inp_list, corr, flow, iter32=(n == 3),
+                                                          iter16=(n >= 2), need_mask=need_mask)
+        finally:
+            self.update_block.inplace_state = False
         delta_flow[:, 1] = 0.0          # stereo: project onto the epipolar line
         coords1.add_(delta_flow)
         for dst, src in zip(net_state, nets):

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import conv2d, get_backend
+from .conv import conv2d, conv2d_gate_out, conv2d_gate_zr, get_backend, hip_eligible
 
 
 def _batch_dense(t, hw):
@@ -79,7 +79,8 @@ class ConvGRU(nn.Module):
             self._zr_key = key
         return self._zr
 
-    def forward(self, h, cz, cr, cq, *x_list):
+    def forward(self, h, cz, cr, cq, *x_list, out=None):
+        """`out` (optional, may be `h`): where the new hidden state is written."""
         _ffi.require_gpu(h, cz, cr, cq, *x_list)
         _ffi.require_no_grad(h, cz, cr, cq, *x_list)
         B, Ch, H, W = h.shape
@@ -89,6 +90,12 @@ class ConvGRU(nn.Module):
         if not _batch_dense(h, HW):
             h = h.contiguous()
         cz, cr, cq = [t if _batch_dense(t, HW) else t.contiguous() for t in (cz, cr, cq)]
+
+        if hip_eligible(self.convq) and Ch % 64 == 0:
+            # gates live in the convolution epilogues: two launches per GRU, no z|r / q
+            # pre-activation tensors, no torch.cat (operands are read in place)
+            z, rh = conv2d_gate_zr([h, *x_list], self._merged_zr(), cz, cr, h)
+            return conv2d_gate_out([rh, *x_list], self.convq, cq, z, h, out=out)
 
         if get_backend() == "miopen":
             # vendor convolutions want one dense operand: build [h | x] once and
@@ -109,7 +116,8 @@ class ConvGRU(nn.Module):
         _ffi.check(rc, "dkt_gru_gate_zr")
         aq = conv2d(q_in, self.convq)
         _ffi.require_gpu(aq)
-        out = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty((B, Ch, H, W), device=h.device, dtype=torch.float32)
         # q = tanh(aq+cq); h' = (1-z)*h + z*q
         rc = L.dkt_gru_gate_out(aq.data_ptr(), cq.data_ptr(), cq.stride(0), z.data_ptr(),
                                 h.data_ptr(), h.stride(0), out.data_ptr(), out.stride(0),
@@ -139,8 +147,14 @@ class BasicMotionEncoder(nn.Module):
         cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
         flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
                      getattr(self, self._branch[1]), relu=True)
-        out = conv2d([cor, flo], self.conv, relu=True)
-        return torch.cat([out, flow], dim=1)
+        # [conv output (126/127 ch) | flow]: the convolution writes straight into the first
+        # channels of the 128-channel motion-feature buffer (no torch.cat of the big part)
+        B, _, H, W = flow.shape
+        nout = self.conv.weight.shape[0]
+        feat = torch.empty((B, nout + flow.shape[1], H, W), device=flow.device, dtype=torch.float32)
+        conv2d([cor, flo], self.conv, relu=True, out=feat[:, :nout])
+        feat[:, nout:] = flow
+        return feat
 
 
 class BasicMotionEncoderIGEV(BasicMotionEncoder):
@@ -201,21 +215,26 @@ class BasicMultiUpdateBlock(nn.Module):
             nn.ReLU(inplace=True),
             nn.Conv2d(256, (factor ** 2) * 9, 1, padding=0))
 
+    #: harness switch: GRUs overwrite their hidden-state tensors instead of allocating new ones
+    #: (the reference rebinds net[i] to a fresh tensor; nothing else may hold the old one)
+    inplace_state = False
+
     def _gru_stack(self, net, inp, fine, mid, coarse, motion, it_fine, it_mid, it_coarse):
         n = self.args.n_gru_layers
+        o = (lambda t: t) if self.inplace_state else (lambda t: None)
         if it_coarse:
-            net[2] = coarse(net[2], *(inp[2]), pool2x(net[1]))
+            net[2] = coarse(net[2], *(inp[2]), pool2x(net[1]), out=o(net[2]))
         if it_mid:
             if n > 2:
-                net[1] = mid(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+                net[1] = mid(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]), out=o(net[1]))
             else:
-                net[1] = mid(net[1], *(inp[1]), pool2x(net[0]))
+                net[1] = mid(net[1], *(inp[1]), pool2x(net[0]), out=o(net[1]))
         if it_fine:
             mf = motion()
             if n > 1:
-                net[0] = fine(net[0], *(inp[0]), mf, interp(net[1], net[0]))
+                net[0] = fine(net[0], *(inp[0]), mf, interp(net[1], net[0]), out=o(net[0]))
             else:
-                net[0] = fine(net[0], *(inp[0]), mf)
+                net[0] = fine(net[0], *(inp[0]), mf, out=o(net[0]))
         return net
 
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True,

@@ -176,6 +176,23 @@ int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long
                     float *out, long out_bstride, int B, int H, int W, int Cout, int KH, int KW,
                     int relu, int passes, int device, void *stream);
 
+/* ConvGRU with the gate arithmetic fused into the convolution epilogues (core/update.py:23-32):
+ * no z|r / q pre-activation tensors ever reach HBM.
+ *   gate_zr : merged convz|convr over [h | x...] (2*Ch outputs, packed as one layer):
+ *             z = sigmoid(conv_z + cz) -> z;  rh = sigmoid(conv_r + cr) * h -> rh
+ *   gate_out: convq over [rh | x...]:  hout = (1 - z)*h + z*tanh(conv_q + cq)   (hout may alias h)
+ * Ch must be a multiple of 64 for gate_zr.  Same arithmetic as dkt_gru_gate_zr/_out. */
+int dkt_conv2d_f16s_gate_zr(const float *const *src, const int *src_channels, const long *src_bstride, int nsrc,
+                            const void *w_hi, const void *w_lo, const float *bias, float out_scale,
+                            const float *cz, long cz_bstride, const float *cr, long cr_bstride,
+                            const float *h, long h_bstride, float *z, long z_bstride, float *rh, long rh_bstride,
+                            int B, int H, int W, int Ch, int KH, int KW, int passes, int device, void *stream);
+int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_channels, const long *src_bstride, int nsrc,
+                             const void *w_hi, const void *w_lo, const float *bias, float out_scale,
+                             const float *cq, long cq_bstride, const float *z, long z_bstride,
+                             const float *h, long h_bstride, float *hout, long hout_bstride,
+                             int B, int H, int W, int Ch, int KH, int KW, int passes, int device, void *stream);
+
 /* ---- streaming helpers around the convolutions ---------------------------------------- */
 
 /* pool2x / interp of the update block (core/update.py:87-95): avg_pool2d(x, 3, stride=2,
