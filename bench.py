@@ -195,25 +195,24 @@ def main():
         look_events.clear()
         conv_events = []
         import dkt_stereo_amd.update as upd
-        real_conv2d = upd.conv2d
-        zr_layer_id = [None]
+        real_gate_zr = upd.conv2d_gate_zr
 
-        def timed_conv2d(x, layer, relu=False):
-            big = isinstance(x, (list, tuple)) and layer.weight.shape[0] == 256 and x[0].shape[2] == h4 \
-                and sum(t.shape[1] for t in x) == 384
+        def timed_gate_zr(x, layer, cz, cr, h):
+            # gru08: merged z|r convolution (384 -> 256, 3x3) with the gate epilogue, finest scale
+            big = layer.weight.shape[0] == 256 and h.shape[2] == h4 and sum(t.shape[1] for t in x) == 384
             if not big:
-                return real_conv2d(x, layer, relu)
+                return real_gate_zr(x, layer, cz, cr, h)
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ea.record()
-            y = real_conv2d(x, layer, relu)
+            y = real_gate_zr(x, layer, cz, cr, h)
             eb.record()
             conv_events.append((ea, eb))
             return y
 
-        upd.conv2d = timed_conv2d
+        upd.conv2d_gate_zr = timed_gate_zr
         step()
         torch.cuda.synchronize()
-        upd.conv2d = real_conv2d
+        upd.conv2d_gate_zr = real_gate_zr
         rs.CORR_IMPLEMENTATIONS = real_impls
         model.use_hip_graph = True
         empty = []
@@ -274,7 +273,7 @@ def main():
         # MFMA-bound; `achieved` counts the fp16 MFMA flops it executes per launch
         # (passes x 2*H*W*Cin*9*Cout; the fp32-equivalent algorithmic figure is 1/passes of it)
         # against the dense fp16 MFMA peak.
-        "roofline": {"kernel": "conv2d_f16s_kernel (dkt_conv2d_f16s), gru08 z|r 384->256 3x3 @%dx%d" % (h4, w4),
+        "roofline": {"kernel": "conv2d_f16s_kernel (dkt_conv2d_f16s_gate_zr), gru08 z|r 384->256 3x3 + gate epilogue @%dx%d" % (h4, w4),
                      "bound": "mfma", "achieved": conv_tflops_exec, "peak": FP16_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": conv_tflops_exec / FP16_MFMA_PEAK_TFLOPS, "traffic": None,
                      "algorithmic_flops_per_launch_fp32_equiv": conv_alg_flops, "mfma_passes": passes,
