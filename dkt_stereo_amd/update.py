@@ -18,6 +18,7 @@ What differs from the reference is how a GRU step is evaluated (core/update.py:2
 Convolutions go through ``dkt_stereo_amd.conv.conv2d`` (see that module).
 Inference only.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -26,6 +27,11 @@ import torch.nn.functional as F
 
 from . import _ffi
 from .conv import conv2d, conv2d_gate_out, conv2d_gate_zr, get_backend, hip_eligible
+
+
+#: evaluate the GRU gates inside the convolution epilogues (dkt_conv2d_f16s_gate_zr/_out)
+#: instead of the two streaming gate kernels
+FUSE_GATES = os.environ.get("DKT_FUSE_GATES", "1") != "0"
 
 
 def _batch_dense(t, hw):
@@ -91,7 +97,7 @@ class ConvGRU(nn.Module):
             h = h.contiguous()
         cz, cr, cq = [t if _batch_dense(t, HW) else t.contiguous() for t in (cz, cr, cq)]
 
-        if hip_eligible(self.convq) and Ch % 64 == 0:
+        if FUSE_GATES and hip_eligible(self.convq) and Ch % 64 == 0:
             # gates live in the convolution epilogues: two launches per GRU, no z|r / q
             # pre-activation tensors, no torch.cat (operands are read in place)
             z, rh = conv2d_gate_zr([h, *x_list], self._merged_zr(), cz, cr, h)
