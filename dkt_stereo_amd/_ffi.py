@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdktstereo.so")
+LIB_PATH = os.environ.get("DKT_LIB_PATH") or os.path.join(_HERE, "lib", "libdktstereo.so")
 
 _c_f32p = ctypes.c_void_p
 _i, _l, _f, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
@@ -23,6 +23,8 @@ _lp = ctypes.POINTER(ctypes.c_long)
 SIGNATURES = {
     "dkt_corr1d_build": [_vp, _vp, _pp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_corr1d_lookup": [_pp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_corr1d_skew": [_pp, _pp, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_corr1d_lookup_skew": [_pp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_corr1d_lookup_otf": [_vp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_pool_w": [_vp, _vp, _l, _i, _i, _vp],
     "dkt_l2norm_channels": [_vp, _vp, _i, _i, _l, _i, _vp],

@@ -12,6 +12,8 @@ them unchanged:
 Inference only (the reference's training path needs autograd through
 grid_sample; that is a later row of SURVEY.md section 8f).
 """
+import os
+
 import torch
 
 from . import _ffi
@@ -43,7 +45,7 @@ def _build_pyramid(fmap1, fmap2, num_levels, divisor, out=None):
     return pyr
 
 
-def _lookup(pyramid, coords, radius, w2):
+def _lookup(pyramid, coords, radius, w2, skewed=False):
     _ffi.require_gpu(coords)
     B, _, H, W1 = coords.shape
     if coords.stride(3) != 1 or coords.stride(2) != W1:
@@ -52,10 +54,20 @@ def _lookup(pyramid, coords, radius, w2):
     K = 2 * radius + 1
     out = torch.empty((B, L * K, H, W1), device=coords.device, dtype=torch.float32)
     # only channel 0 (x) is read, like coords[:, :1] in core/corr.py:129
-    rc = _ffi.lib().dkt_corr1d_lookup(_ffi.ptr_array(pyramid), coords.data_ptr(), coords.stride(0),
-                                      out.data_ptr(), B, H, W1, w2, L, radius,
-                                      _ffi.device_of(coords), _ffi.stream_of(coords))
-    _ffi.check(rc, "dkt_corr1d_lookup")
+    fn = _ffi.lib().dkt_corr1d_lookup_skew if skewed else _ffi.lib().dkt_corr1d_lookup
+    rc = fn(_ffi.ptr_array(pyramid), coords.data_ptr(), coords.stride(0), out.data_ptr(), B, H, W1, w2, L,
+            radius, _ffi.device_of(coords), _ffi.stream_of(coords))
+    _ffi.check(rc, "dkt_corr1d_lookup_skew" if skewed else "dkt_corr1d_lookup")
+    return out
+
+
+def _skew_pyramid(pyramid, B, H, W1, W2, out=None):
+    """dkt_corr1d_skew: diagonal-major copy of every level (see corr1d_skew.hip)."""
+    if out is None:
+        out = [torch.empty_like(p) for p in pyramid]
+    rc = _ffi.lib().dkt_corr1d_skew(_ffi.ptr_array(pyramid), _ffi.ptr_array(out), B, H, W1, W2, len(pyramid),
+                                    _ffi.device_of(pyramid[0]), _ffi.stream_of(pyramid[0]))
+    _ffi.check(rc, "dkt_corr1d_skew")
     return out
 
 
@@ -64,23 +76,33 @@ class CorrBlock1D:
     ``__call__`` reads (the reference also stores one more pooled level that
     nothing ever reads)."""
 
+    #: "skew": lookups read a diagonal-major copy of the pyramid (neighbouring pixels read
+    #: neighbouring floats when disparity is locally smooth); "rows": the reference layout.
+    #: Both give bit-identical results.  ``corr_pyramid`` is always the reference layout.
+    lookup_layout = os.environ.get("DKT_LOOKUP_LAYOUT", "skew")
+
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         self.num_levels = num_levels
         self.radius = radius
         self._w2 = fmap2.shape[3]
         self.corr_pyramid = None
+        self._skew = None
         self.rebuild(fmap1, fmap2)
 
     def rebuild(self, fmap1, fmap2):
         """Recomputes the pyramid for a new pair INTO the existing tensors (same shapes):
         lets a captured HIP graph of the lookup keep its pointers."""
-        C = fmap1.shape[1]
+        B, C, H, W1 = fmap1.shape
         # corr / sqrt(C) (core/corr.py:156); the kernel divides like the reference
         self.corr_pyramid = _build_pyramid(fmap1.float(), fmap2.float(), self.num_levels,
                                            float(torch.sqrt(torch.tensor(C).float())),
                                            out=self.corr_pyramid)
+        if self.lookup_layout == "skew":
+            self._skew = _skew_pyramid(self.corr_pyramid, B, H, W1, self._w2, out=self._skew)
 
     def __call__(self, coords):
+        if self._skew is not None:
+            return _lookup(self._skew, coords, self.radius, self._w2, skewed=True)
         return _lookup(self.corr_pyramid, coords, self.radius, self._w2)
 
     @staticmethod
@@ -117,6 +139,9 @@ class CorrBlock1D_Cosine(CorrBlock1D):
         self.radius = radius
         self._w2 = fmap2.shape[3]
         self.corr_pyramid = _build_pyramid(self._normalise(fmap1), self._normalise(fmap2), num_levels, 1.0)
+        B, _, H, W1 = fmap1.shape
+        self._skew = (_skew_pyramid(self.corr_pyramid, B, H, W1, self._w2)
+                      if self.lookup_layout == "skew" else None)
 
     @staticmethod
     def _normalise(fmap):

@@ -38,6 +38,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CONV_MAX_SRC 4
+// scheduling tunables (swept with tools/sweep_conv_variants.sh)
+#ifndef CONV_AR
+#define CONV_AR 3
+#endif
+#ifndef CONV_SGB_MFMA
+#define CONV_SGB_MFMA 1
+#endif
+#ifndef CONV_SGB_MEM
+#define CONV_SGB_MEM 1
+#endif
+#ifndef CONV_SGB_VALU
+#define CONV_SGB_VALU 3
+#endif
 
 struct ConvArgs {
     const float *src[CONV_MAX_SRC];
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int NITEMS = NPP * 16;         // (pixel, channel pair) items per chunk
     constexpr int IT = (NITEMS + 255) / 256;
     constexpr int NSTEP = KS * KS * 2;       // (tap, 16-channel half) steps per chunk
-    constexpr int AR = (NSTEP % 3 == 0) ? 3 : 2;   // weight-fragment ring (prefetch distance AR-1)
+    constexpr int AR = (NSTEP % 3 == 0 && CONV_AR == 3) ? 3 : 2;   // weight-fragment ring (prefetch distance AR-1)
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 2 * STAGE words
 
     const int tid = threadIdx.x;
@@ -280,10 +293,10 @@ __global__ __launch_bounds__(256, 1) void conv2d_f16s_kernel(ConvArgs a) {
             }
             if (!(ABL & 16)) {
 #pragma unroll
-                for (int i = 0; i < NMMA; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x320, 1, 0);   // 1 VMEM read / DS read / DS write
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+                for (int i = 0; i < NMMA / CONV_SGB_MFMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, CONV_SGB_MFMA, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x320, CONV_SGB_MEM, 0);    // VMEM read / DS read / DS write
+                    __builtin_amdgcn_sched_group_barrier(0x002, CONV_SGB_VALU, 0);   // VALU
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -76,6 +76,17 @@ int dkt_corr1d_lookup(const float *const *pyr, const float *coords_x, long coord
                       float *out, int B, int H, int W1, int W2, int L, int r,
                       int device, void *stream);
 
+/* Diagonal-major ("skewed") copy of the pyramid and the lookup that reads it:
+ *   skew[i][row][s][w1] = pyr[i][row*W1 + w1][(s + (w1 >> i)) mod (W2>>i)],  row = b*H + h
+ * (same sizes as pyr[i]).  Neighbouring pixels with similar disparity then read neighbouring
+ * floats: a wave's tap is one contiguous 256-byte load instead of 64 separate lines
+ * (corr1d_skew.hip).  dkt_corr1d_lookup_skew returns exactly what dkt_corr1d_lookup does. */
+int dkt_corr1d_skew(const float *const *pyr, float *const *skew, int B, int H, int W1, int W2, int L,
+                    int device, void *stream);
+int dkt_corr1d_lookup_skew(const float *const *skew, const float *coords_x, long coords_bstride,
+                           float *out, int B, int H, int W1, int W2, int L, int r,
+                           int device, void *stream);
+
 /* On-the-fly lookup without a volume.  Replaces PytorchAlternateCorrBlock1D
  * (core/corr.py:64-107): samples the (i-times W-pooled) right feature map at
  * the 2r+1 taps and dots it with the left feature vector, / sqrt(C).

@@ -441,3 +441,30 @@ def test_full_size_geo_lookup_properties():
     assert torch.equal(fn.geo_volume_pyramid[1], half)
     for k in range(9):   # level 1 (offset 81): disp/2 = 5
         assert float((out[:, 81 + k] - half[:, 0, 5 + k - 4]).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", list(_cases.CORR_CASES))
+@torch.no_grad()
+def test_skewed_pyramid_lookup_is_bit_identical(name):
+    """The diagonal-major pyramid (dkt_corr1d_skew / dkt_corr1d_lookup_skew) is a pure
+    re-indexing: same values, same taps -> the same bits as the reference-layout lookup,
+    for smooth, random, integral and far out-of-range coordinates and for W1 != W2."""
+    from dkt_stereo_amd.corr import CorrBlock1D, _lookup
+    c = _cases.CORR_CASES[name]
+    f1, f2, coords = _cases.corr_inputs(c)
+    blk = CorrBlock1D(G(f1), G(f2), num_levels=c["L"], radius=c["r"])
+    assert blk._skew is not None and CorrBlock1D.lookup_layout == "skew"
+    rows = _lookup(blk.corr_pyramid, G(coords), c["r"], c["W2"])
+    for cc in (coords, _synth.coords(77, c["B"], c["H"], c["W"], spread=3.0)):
+        assert torch.equal(blk(G(cc)), _lookup(blk.corr_pyramid, G(cc), c["r"], c["W2"]))
+    assert torch.equal(blk(G(coords)), rows)
+    # the skew itself: S[row][s][w1] == P[row*W1 + w1][(s + (w1 >> i)) % W2_i]
+    B, H, W1 = c["B"], c["H"], c["W"]
+    for i, (p, s) in enumerate(zip(blk.corr_pyramid, blk._skew)):
+        wi = c["W2"] >> i
+        P = p.view(B * H, W1, wi).cpu()
+        S = s.view(B * H, wi, W1).cpu()
+        w1 = torch.arange(W1)
+        for sv in (0, 1, wi - 1, wi // 2):
+            col = (sv + (w1 >> i)) % wi
+            assert torch.equal(S[:, sv, :], P[:, w1, col])

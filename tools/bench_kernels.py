@@ -70,9 +70,12 @@ def bench_lookup():
                 coords[:, 0] = xs - 20.3 - 3.0 * torch.sin(torch.arange(H, device=DEV).float() / 9.0).view(1, H, 1)
             else:
                 coords[:, 0] = xs - 60.0 * torch.rand(B, H, W, device=DEV)
+            from dkt_stereo_amd.corr import _lookup
             for variant in ("1", "4"):
                 os.environ["DKT_LOOKUP_VARIANT"] = variant
-                report("lookup v%s B=%d %s" % (variant, B, kind), timeit(lambda: blk(coords), n=200), bytes_=alg)
+                report("lookup rows v%s B=%d %s" % (variant, B, kind),
+                       timeit(lambda: _lookup(blk.corr_pyramid, coords, 4, W), n=200), bytes_=alg)
+            report("lookup skew    B=%d %s" % (B, kind), timeit(lambda: blk(coords), n=200), bytes_=alg)
         os.environ.pop("DKT_LOOKUP_VARIANT", None)
         del blk, f1, f2
 
