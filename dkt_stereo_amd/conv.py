@@ -110,6 +110,38 @@ def hip_eligible(layer):
     return _BACKEND in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2)
 
 
+def direct_eligible(layer):
+    """Layers with very few output channels (3x3, Cout <= 4: flow/disp head) or very few input
+    channels (7x7, Cin <= 4: flow/disp stem) run on the exact-fp32 direct kernel."""
+    if _BACKEND not in _PASSES:
+        return False
+    cout, cin, kh, kw = layer.weight.shape
+    pad = layer.padding
+    pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+    if kh != kw or pad != (kh // 2, kw // 2):
+        return False
+    return (kh == 3 and cout <= 4) or (kh == 7 and cin <= 4)
+
+
+def _conv2d_direct(x, layer, relu, out):
+    _ffi.require_gpu(x)
+    _ffi.require_no_grad(x)
+    if not _dense(x):
+        x = x.contiguous()
+    B, cin, H, W = x.shape
+    cout, _, kh, kw = layer.weight.shape
+    if out is None:
+        out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    w = layer.weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    b = layer.bias
+    rc = _ffi.lib().dkt_conv2d_direct(x.data_ptr(), x.stride(0), w.data_ptr(), None if b is None else b.data_ptr(),
+                                      out.data_ptr(), out.stride(0), B, cin, cout, H, W, kh, kw, int(bool(relu)),
+                                      _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_conv2d_direct")
+    return out
+
+
 class _Operands:
     """The cat operands of one convolution marshalled for the C ABI (keeps them alive)."""
 
@@ -140,6 +172,8 @@ class _Operands:
 def conv2d(x, layer, relu=False, out=None):
     """`out`: optional (B,Cout,H,W) fp32 destination whose batch elements are dense (e.g. a
     channel slice of a wider buffer -- replaces a torch.cat of the result)."""
+    if direct_eligible(layer) and not isinstance(x, (list, tuple)):
+        return _conv2d_direct(x, layer, relu, out)
     if not hip_eligible(layer):
         y = _vendor(x, layer, relu)
         if out is not None:

@@ -204,6 +204,13 @@ int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_channels, c
                              const float *h, long h_bstride, float *hout, long hout_bstride,
                              int B, int H, int W, int Ch, int KH, int KW, int passes, int device, void *stream);
 
+/* Direct exact-fp32 convolution (stride 1, "same" padding) for the two extreme shapes of the
+ * update block: 3x3 with Cout <= 4 (flow_head.conv2 / disp_head.conv2, core/update.py:10) and
+ * 7x7 with Cin <= 4 (convf1 / convd1, core/update.py:75).  w: (Cout,Cin,K,K); optional ReLU. */
+int dkt_conv2d_direct(const float *x, long x_bstride, const float *w, const float *bias,
+                      float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
+                      int KH, int KW, int relu, int device, void *stream);
+
 /* ---- streaming helpers around the convolutions ---------------------------------------- */
 
 /* pool2x / interp of the update block (core/update.py:87-95): avg_pool2d(x, 3, stride=2,

@@ -74,6 +74,24 @@ def test_conv_vs_fp64(shape, backend):
     assert torch.equal(got2, got)
 
 
+@pytest.mark.parametrize("shape", [("head", 1, 256, 2, 23, 70, 3, False), ("disp", 2, 256, 1, 9, 33, 3, False),
+                                   ("stem", 1, 2, 64, 20, 45, 7, True), ("dstem", 2, 1, 64, 11, 34, 7, True),
+                                   ("c4", 1, 40, 4, 8, 8, 3, True)], ids=lambda s: s[0])
+@torch.no_grad()
+def test_direct_conv_vs_fp64(shape):
+    """dkt_conv2d_direct (exact fp32 FMAs): flow/disp head (Cout <= 4) and 7x7 stems (Cin <= 4)."""
+    from dkt_stereo_amd import conv
+    name, B, cin, cout, H, W, k, relu = shape
+    conv.set_backend("f16x3")
+    layer = torch.nn.Conv2d(cin, cout, k, padding=k // 2).to(DEV)
+    assert conv.direct_eligible(layer)
+    x = G(_synth.normal((B, cin, H, W), 95, name, scale=2.0))
+    ref = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=k // 2)
+    ref = ref.clamp_min(0) if relu else ref
+    got = conv.conv2d(x, layer, relu=relu)
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
 @torch.no_grad()
 def test_conv_weight_cache_invalidation():
     from dkt_stereo_amd import conv
