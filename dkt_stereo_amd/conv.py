@@ -111,8 +111,9 @@ def hip_eligible(layer):
 
 
 def direct_eligible(layer):
-    """Layers with very few output channels (3x3, Cout <= 4: flow/disp head) or very few input
-    channels (7x7, Cin <= 4: flow/disp stem) run on the exact-fp32 direct kernel."""
+    """The 7x7 flow/disp stems (Cin <= 4) run on the exact-fp32 direct kernel: 23 us vs 53 us
+    (+ a separate ReLU) on the vendor path.  The kernel also handles 3x3 layers with Cout <= 4
+    (flow/disp head), but at 163 us it loses to the MFMA kernel's 76 us and is not selected."""
     if _BACKEND not in _PASSES:
         return False
     cout, cin, kh, kw = layer.weight.shape
@@ -120,7 +121,7 @@ def direct_eligible(layer):
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
     if kh != kw or pad != (kh // 2, kw // 2):
         return False
-    return (kh == 3 and cout <= 4) or (kh == 7 and cin <= 4)
+    return kh == 7 and cin <= 4
 
 
 def _conv2d_direct(x, layer, relu, out):
@@ -172,6 +173,8 @@ class _Operands:
 def conv2d(x, layer, relu=False, out=None):
     """`out`: optional (B,Cout,H,W) fp32 destination whose batch elements are dense (e.g. a
     channel slice of a wider buffer -- replaces a torch.cat of the result)."""
+    if isinstance(x, (list, tuple)) and len(x) == 1:
+        x = x[0]
     if direct_eligible(layer) and not isinstance(x, (list, tuple)):
         return _conv2d_direct(x, layer, relu, out)
     if not hip_eligible(layer):

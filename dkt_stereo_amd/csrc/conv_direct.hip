@@ -26,7 +26,10 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(DirectArgs a) {
     constexpr int TR = 8, TC = 32;
     constexpr int PR = TR + 2 * HALO, PC = TC + 2 * HALO;
     constexpr int PCP = PC | 1;                         // odd pitch: conflict-free row-shifted reads
+    constexpr int TAPS = KS * KS;
     __shared__ float patch[CC][PR][PCP];
+    // weights of the staged channels, [c][tap][TO]: one broadcast ds_read_b64/b128 per (c, tap)
+    __shared__ __attribute__((aligned(16))) float wl[CC][TAPS][TO];
     const int tid = threadIdx.x;
     const int tx = tid & 31, ty = tid >> 5;
     const int w0 = (blockIdx.x % a.tiles_w) * TC, h0 = (blockIdx.x / a.tiles_w) * TR;
@@ -48,21 +51,22 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(DirectArgs a) {
                 v = xb[(long)(c0 + c) * HW + (long)ih * a.W + iw];
             patch[c][r][q] = v;
         }
+        for (int i = tid; i < CC * TAPS * TO; i += 256) {
+            const int o = i % TO, t = (i / TO) % TAPS, c = i / (TO * TAPS);
+            float v = 0.0f;
+            if (c0 + c < a.Cin && co0 + o < a.Cout) v = a.w[((long)(co0 + o) * a.Cin + (c0 + c)) * TAPS + t];
+            wl[c][t][o] = v;
+        }
         __syncthreads();
-        const int cn = (a.Cin - c0) < CC ? (a.Cin - c0) : CC;
-        for (int c = 0; c < cn; ++c) {
-            // wave-uniform weight row of every owned output channel for this input channel
-            const float *wc = a.w + ((long)co0 * a.Cin + (c0 + c)) * (KS * KS);
+#pragma unroll 2
+        for (int c = 0; c < CC; ++c) {
 #pragma unroll
             for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < KS; ++dx) {
                     const float v = patch[c][ty + dy][tx + dx];
 #pragma unroll
-                    for (int o = 0; o < TO; ++o) {
-                        const float wv = (co0 + o < a.Cout) ? wc[(long)o * a.Cin * (KS * KS) + dy * KS + dx] : 0.0f;
-                        acc[o] = __fmaf_rn(v, wv, acc[o]);
-                    }
+                    for (int o = 0; o < TO; ++o) acc[o] = __fmaf_rn(v, wl[c][dy * KS + dx][o], acc[o]);
                 }
         }
     }
