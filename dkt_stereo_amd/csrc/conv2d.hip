@@ -33,6 +33,7 @@
 // double buffered: the fp32 loads of chunk c+1 are in flight under the MFMAs of
 // chunk c; one barrier per chunk.
 #include "dkt_common.h"
+#include <cstdlib>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,6 +42,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // scheduling tunables (swept with tools/sweep_conv_variants.sh)
 #ifndef CONV_AR
 #define CONV_AR 3
+#endif
+#ifndef CONV_ABL
+#define CONV_ABL 0        // timing-only ablation builds (tools/sweep_conv_variants.sh); 0 in the product
+#endif
+#ifndef CONV_MIN_BLOCKS
+#define CONV_MIN_BLOCKS 2    // blocks per CU the register budget is capped for (256 VGPRs)
+#endif
+#ifndef CONV_AR_NF1
+#define CONV_AR_NF1 3
 #endif
 #ifndef CONV_SGB_MFMA
 #define CONV_SGB_MFMA 1
@@ -64,6 +74,7 @@ struct ConvArgs {
     float *out;
     long out_bs;
     int H, W, Cout, CoutPad, nch16, tiles_w;
+    int tiles_xy, n_co, total_tiles;   // persistent tile stream: id = (b*n_co + co block)*tiles_xy + xy
     int relu;
     // fused ConvGRU gate epilogues (core/update.py:27-31), epi = 0 none;
     //   1: merged z|r convolution, Cout = 2*Ch:  co <  Ch: z  = sigmoid(v + cz)        -> out  (z)
@@ -100,8 +111,8 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv2d_f16s_kernel(ConvArgs a) {
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL>
+__global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int HALO = KS / 2;
     constexpr int TR = NF * WN;              // output rows per block
     constexpr int PR = TR + 2 * HALO;        // patch rows
@@ -111,98 +122,136 @@ __global__ __launch_bounds__(256, 1) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int PLANE = NPP * PITCH;       // words per (hi or lo) plane
     constexpr int NPLANES = PASSES == 3 ? 2 : 1;   // x_lo is only needed for the w_hi*x_lo pass
     constexpr int STAGE = PLANE * NPLANES;
-    constexpr int NITEMS = NPP * 16;         // (pixel, channel pair) items per chunk
-    constexpr int IT = (NITEMS + 255) / 256;
     constexpr int NSTEP = KS * KS * 2;       // (tap, 16-channel half) steps per chunk
-    constexpr int AR = (NSTEP % 3 == 0 && CONV_AR == 3) ? 3 : 2;   // weight-fragment ring (prefetch distance AR-1)
-    extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 2 * STAGE words
+    // weight-fragment ring (prefetch distance AR-1 steps).  A step of an NF=1 tile is only
+    // 6 MFMAs (~80 ns): its ring is deeper so that the L2 latency of the weights stays covered.
+    constexpr int AR_WANT = NF == 1 ? CONV_AR_NF1 : CONV_AR;
+    constexpr int AR = (NSTEP % AR_WANT == 0) ? AR_WANT : 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 2 * STAGE words (+ 8 dummy)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const int tile = blockIdx.x;
-    const int w0 = (tile % a.tiles_w) * 32;
-    const int h0 = (tile / a.tiles_w) * TR;
-    const int co_blk = blockIdx.y * (64 * WM);
-    const int b = blockIdx.z;
     const long HW = (long)a.H * a.W;
+    // Persistent block: tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...; the (tile, chunk)
+    // pairs of a block form ONE software-pipelined stream, so that only the block's first
+    // chunk is staged with its global-load latency exposed (for a 64->64 layer -- two chunks
+    // per tile -- prologue + epilogue used to be 52 of 113 us).
+    // tile id = (b * n_co + co block) * tiles_xy + spatial tile.
+    auto decode = [&](int t, int &th0, int &tw0, int &tco, int &tb) {
+        const int xy = t % a.tiles_xy, r = t / a.tiles_xy;
+        tw0 = (xy % a.tiles_w) * 32;
+        th0 = (xy / a.tiles_w) * TR;
+        tco = (r % a.n_co) * (64 * WM);
+        tb = r / a.n_co;
+    };
+    int h0, w0, co_blk, b;            // tile being computed
+    int tile = blockIdx.x;
+    decode(tile, h0, w0, co_blk, b);
 
-    // ---- staging: item = (patch pixel pp, channel pair cp), item = tid + 256*it.
-    // The (pp, cp) -> address arithmetic is recomputed per chunk (a few VALU ops per
-    // item against ~14k MFMA cycles per chunk) rather than held in 2*IT registers.
-    // Both halves are BRANCH-FREE (clamped addresses + selects, surplus items write a
-    // dummy LDS word) and take an item range, so that slices of them can sit inside
-    // the MFMA steps of the previous chunk and be interleaved with the MFMAs.
-    float2 sreg[IT];
-    const float *sbase = nullptr;   // source plane of the chunk being staged (wave-uniform)
-    int snch = 0;
-    auto stage_select = [&](int chunk) {
+    // ---- staging.  Wave w stages channels 8w..8w+7 of every 32-channel chunk; its lanes walk
+    // the patch pixels (pp = lane + 64*it).  The channel is wave-uniform, so a channel plane's
+    // base address lives in SGPRs and the per-lane part of the address -- the pixel's byte
+    // offset in a plane -- is computed once per TILE (SIT registers), not per chunk: staging
+    // costs ~7 VALU instructions per value (select, clamp, 2 cvt + sub + cvt for the hi/lo
+    // split, half a pack) instead of ~30.  (PMC on a 64->64 layer before this form: 18 VALU
+    // instructions per MFMA, VALU port 50 % busy, MFMA pipe 22 %.)  Each lane writes its
+    // pixel's 8 channels as one ds_write_b128 per plane.  Both halves take a SLICE range
+    // (slice = pixel slot x channel pair) so that they can be spread over the MFMA steps of the
+    // previous chunk.
+    constexpr int SIT = (NPP + 63) / 64;      // pixel slots per lane
+    constexpr int NSL = SIT * 4;              // slices per chunk
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    unsigned spix[SIT];                       // byte offset of the slot's pixel inside a channel plane
+    bool sok[SIT];                            // the slot's pixel lies inside the image
+    float sreg[SIT][8];
+    unsigned shw[SIT][4], slw[SIT][4];        // converted (hi, lo) fp16 pairs awaiting the LDS write
+    const float *sbase = nullptr;             // plane of the first channel this wave stages (wave-uniform)
+    int snch = 0;                             // valid channels from there on (<= 0: all padding)
+    auto stage_tile = [&](int th0, int tw0) {
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int pp = lane + 64 * it;
+            const int pr = pp / PC, pc = pp - pr * PC;
+            const int ih = th0 - HALO + pr, iw = tw0 - HALO + pc;
+            sok[it] = pp < NPP && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            spix[it] = sok[it] ? (unsigned)(ih * a.W + iw) * 4u : 0u;
+        }
+    };
+    auto stage_select = [&](int tb, int chunk) {
         int s = 0, c0 = chunk * 32;
         while (s + 1 < a.nsrc && c0 >= ((a.src_ch[s] + 31) & ~31)) {
             c0 -= (a.src_ch[s] + 31) & ~31;
             ++s;
         }
-        sbase = a.src[s] + (long)b * a.src_bs[s] + (long)c0 * HW;
-        snch = a.src_ch[s] - c0;    // valid channels from c0 on (may exceed 32)
+        const int cb = c0 + 8 * swave;
+        snch = a.src_ch[s] - cb;
+        sbase = a.src[s] + (long)tb * a.src_bs[s] + (long)(snch > 0 ? cb : 0) * HW;
     };
-    auto stage_load = [&](int it0, int it1) {
-        int t = tid;
-        asm volatile("" : "+v"(t));          // opaque: stops the plan being hoisted into live registers
+    auto stage_load = [&](int k0, int k1) {
 #pragma unroll
-        for (int it = it0; it < it1; ++it) {
-            if (it >= IT) break;
-            const int item = t + 256 * it;
-            const int cp = item / NPP, pp = item - cp * NPP;
-            const int pr = pp / PC, pc = pp - pr * PC;
-            const int ih = h0 - HALO + pr, iw = w0 - HALO + pc;
-            const bool ok = item < NITEMS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            const int ch = 2 * cp;
-            const bool ok0 = ok && ch < snch, ok1 = ok && ch + 1 < snch;
-            const int off = ok ? ih * a.W + iw : 0;
-            const float l0 = sbase[(long)(ok0 ? ch : 0) * HW + off];
-            const float l1 = sbase[(long)(ok1 ? ch + 1 : 0) * HW + off];
-            sreg[it] = make_float2(ok0 ? l0 : 0.0f, ok1 ? l1 : 0.0f);
+        for (int k = k0; k < k1; ++k) {
+            if (k >= NSL) break;
+            const int it = k >> 2, q = k & 3;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                // unconditional load from a clamped (valid) plane; padding channels and pixels
+                // outside the image are zeroed when the value is converted (stage_store) -- a
+                // select here would tie an s_waitcnt vmcnt(0) to every load
+                const int j = 2 * q + jj;
+                const int jc = min(j, max(snch, 1) - 1);                     // wave-uniform
+                const char *pj = (const char *)(sbase + (long)jc * HW);
+                sreg[it][j] = *(const float *)(pj + spix[it]);
+            }
         }
     };
-    auto stage_store = [&](unsigned *buf, int it0, int it1) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
+    auto stage_store = [&](unsigned *buf, int k0, int k1) {
 #pragma unroll
-        for (int it = it0; it < it1; ++it) {
-            if (it >= IT) break;
-            const int item = t + 256 * it;
-            const int cp = item / NPP, pp = item - cp * NPP;
-            unsigned *dst = item < NITEMS ? buf + pp * PITCH + cp : lds + 2 * STAGE;   // surplus -> dummy
-            float x0 = fminf(fmaxf(sreg[it].x, -65504.0f), 65504.0f);
-            float x1 = fminf(fmaxf(sreg[it].y, -65504.0f), 65504.0f);
+        for (int k = k0; k < k1; ++k) {
+            if (k >= NSL) break;
+            const int it = k >> 2, q = k & 3;
+            const float v0 = (2 * q < snch && sok[it]) ? sreg[it][2 * q] : 0.0f;
+            const float v1 = (2 * q + 1 < snch && sok[it]) ? sreg[it][2 * q + 1] : 0.0f;
+            const float x0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);
+            const float x1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
             const _Float16 h0_ = (_Float16)x0, h1_ = (_Float16)x1;
-            dst[0] = pack_h2(h0_, h1_);
-            if (NPLANES == 2) {
-                const _Float16 l0 = (_Float16)(x0 - (float)h0_), l1 = (_Float16)(x1 - (float)h1_);
-                dst[item < NITEMS ? PLANE : 1] = pack_h2(l0, l1);
+            shw[it][q] = pack_h2(h0_, h1_);
+            if (NPLANES == 2) slw[it][q] = pack_h2((_Float16)(x0 - (float)h0_), (_Float16)(x1 - (float)h1_));
+            if (q == 3) {
+                const int pp = lane + 64 * it;
+                unsigned *dst = pp < NPP ? buf + pp * PITCH + 4 * swave : lds + 2 * STAGE;   // surplus lanes -> dummy
+                *(uint4 *)dst = make_uint4(shw[it][0], shw[it][1], shw[it][2], shw[it][3]);
+                if (NPLANES == 2)
+                    *(uint4 *)(dst + (pp < NPP ? PLANE : 4)) = make_uint4(slw[it][0], slw[it][1], slw[it][2], slw[it][3]);
             }
         }
     };
 
     f32x16 acc[2][NF];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NF; ++n)
+            for (int n = 0; n < NF; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    };
+    zero_acc();
 
     const int li = lane & 31, kg = lane >> 5;
-    const int co_w = co_blk + wm * 64;                 // this wave's first output channel
-    const bool wave_on = co_w < a.CoutPad;             // waves past the (64-padded) channel count idle
-    // weight fragment base (halves): ((tap*nch16 + ch16)*CoutPad + co)*16 + kg*8
-    const long wlane = ((long)((wave_on ? co_w : 0) + li)) * 16 + kg * 8;
+    // weight fragment base (halves): ((tap*nch16 + ch16)*CoutPad + co)*16 + kg*8; waves past
+    // the (64-padded) channel count idle on clamped weights
+    auto wlane_of = [&](int tco) {
+        const int cw = tco + wm * 64;
+        return ((long)((cw < a.CoutPad ? cw : 0) + li)) * 16 + kg * 8;
+    };
+    long wl_cur = wlane_of(co_blk), wl_nxt = wl_cur;   // weight bases of the computed / the following tile
     const long wstep = (long)a.CoutPad * 16;           // one 16-channel slab
     const int nchunks = a.nch16 / 2;
 
     f16x8 Ahi[AR][2], Alo[AR][2];
     f16x8 Bhi[2][NF], Blo[2][NF];
-    auto loadA = [&](int slot, int chunk, int step) {
+    auto loadA = [&](int slot, long wlane, int chunk, int step) {
         const int tap = step >> 1, kh = step & 1;
         const long wbase = ((long)tap * a.nch16 + (chunk * 2 + kh)) * wstep + wlane;
 #pragma unroll
@@ -256,131 +305,162 @@ __global__ __launch_bounds__(256, 1) void conv2d_f16s_kernel(ConvArgs a) {
     // second half); a sched_group_barrier pattern asks for ~1 memory op + 3 VALU per MFMA.
     // Idle waves (co >= CoutPad) run the same stream on clamped weights and store nothing:
     // a wave-uniform branch here would split the scheduling region.
-    constexpr int HALF = NSTEP / 2;
-    constexpr int PER = (IT + HALF - 1) / HALF;
-    constexpr int NMMA = 2 * NF * PASSES;
-    stage_select(0);
-    stage_load(0, IT);
-    stage_store(lds, 0, IT);
-    __syncthreads();
+    auto epilogue = [&]() {
+        // ---- epilogue: un-scale, bias, optional ReLU, NCHW stores (128-byte rows) ----
+        const int co_w = co_blk + wm * 64;                 // this wave's first output channel
+        if (co_w >= a.CoutPad) return;                     // idle wave
+        // this lane's 32 output channels: co = co_lane + m*32 + (r&3) + 8*(r>>2); their biases
+        // are fetched as one batch of independent loads (clamped index, no per-element branch)
+        const int co_lane = co_w + 4 * kg;
+        float bv[2][16];
 #pragma unroll
-    for (int s = 0; s < AR - 1; ++s) loadA(s, 0, s);
-    loadB(0, lds, 0);
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = c + 1 < nchunks;
-        const unsigned *cur = lds + (c & 1) * STAGE;
-        unsigned *nxt = lds + ((c + 1) & 1) * STAGE;
-        stage_select(more ? c + 1 : c);      // last chunk re-stages itself into the idle buffer (harmless)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            // weights for step s+AR-1 (possibly the next chunk's first steps)
-            const int sa = s + AR - 1;
-            if (!(ABL & 1)) {
-                if (sa < NSTEP) loadA(sa % AR, c, sa);
-                else loadA(sa % AR, more ? c + 1 : c, sa - NSTEP);
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_lane + m * 32 + (r & 3) + 8 * (r >> 2);
+                bv[m][r] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f;
             }
-            if (s + 1 < NSTEP && !(ABL & 2)) loadB((s + 1) & 1, cur, s + 1);
-            if (!(ABL & 4)) {
-                if (s < HALF) stage_load(s * PER, (s + 1) * PER);
-                else stage_store(nxt, (s - HALF) * PER, (s - HALF + 1) * PER);
-            }
-            if (!(ABL & 8)) mma(s % AR, s & 1);
-            else {
+        const bool all_co = co_w + 64 <= a.Cout;            // wave-uniform: no channel guard needed
+        const int iHW = (int)HW;
+        if (a.epi == 0) {
+            float *ob = a.out + (long)b * a.out_bs + (long)co_lane * HW;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(Ahi[s % AR][m]), "v"(Alo[s % AR][m]));
+            for (int n = 0; n < NF; ++n) {
+                const int oh = h0 + wn * NF + n, ow = w0 + li;
+                if (oh >= a.H || ow >= a.W) continue;
+                float *op = ob + (long)oh * a.W + ow;
 #pragma unroll
-                for (int n = 0; n < NF; ++n) asm volatile("" ::"v"(Bhi[s & 1][n]), "v"(Blo[s & 1][n]));
-            }
-            if (!(ABL & 16)) {
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int i = 0; i < NMMA / CONV_SGB_MFMA; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, CONV_SGB_MFMA, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x320, CONV_SGB_MEM, 0);    // VMEM read / DS read / DS write
-                    __builtin_amdgcn_sched_group_barrier(0x002, CONV_SGB_VALU, 0);   // VALU
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
+                        float v = acc[m][n][r] * a.out_scale + bv[m][r];
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        if (all_co || co_lane + dco < a.Cout) op[dco * iHW] = v;
+                    }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            return;
         }
-        __syncthreads();
-        if (more && !(ABL & 2)) loadB(0, nxt, 0);      // NSTEP is even: step 0 always uses B slot 0
-    }
-
-    // ---- epilogue: un-scale, bias, optional ReLU, NCHW stores (128-byte rows) ----
-    if (!wave_on) return;
-    // this lane's 32 output channels: co = co_lane + m*32 + (r&3) + 8*(r>>2); their biases
-    // are fetched as one batch of independent loads (clamped index, no per-element branch)
-    const int co_lane = co_w + 4 * kg;
-    float bv[2][16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_lane + m * 32 + (r & 3) + 8 * (r >> 2);
-            bv[m][r] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f;
-        }
-    const bool all_co = co_w + 64 <= a.Cout;            // wave-uniform: no channel guard needed
-    const int iHW = (int)HW;
-    if (a.epi == 0) {
-        float *ob = a.out + (long)b * a.out_bs + (long)co_lane * HW;
+        // ---- fused GRU gates (gru_gates.hip arithmetic with hardware exp/rcp) ----
+        const int Ch = a.epi == 1 ? a.Cout / 2 : a.Cout;
+        const bool second = a.epi == 1 && co_w >= Ch;       // wave-uniform: this wave owns r channels
+        const int cg = co_lane - (second ? Ch : 0);         // channel inside the Ch-wide gate tensors
+        const float *pc = (second ? a.e_c1 : a.e_c0) + (long)b * (second ? a.e_c1_bs : a.e_c0_bs) + (long)cg * HW;
+        const float *pz = a.e_c1 + (long)b * a.e_c1_bs + (long)cg * HW;       // epi 2 only
+        const float *ph = a.e_h + (long)b * a.e_h_bs + (long)cg * HW;
+        float *po = (second ? a.out2 + (long)b * a.out2_bs : a.out + (long)b * a.out_bs) + (long)cg * HW;
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
             const int oh = h0 + wn * NF + n, ow = w0 + li;
             if (oh >= a.H || ow >= a.W) continue;
-            float *op = ob + (long)oh * a.W + ow;
+            const long px = (long)oh * a.W + ow;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int mh = 0; mh < 4; ++mh) {
+                // the gate operands of 8 channels are fetched as one batch BEFORE any store (hout
+                // may alias h, so the compiler cannot hoist the loads over stores itself); batches
+                // of 8 rather than 16 keep the kernel inside the 256-VGPR budget of two blocks/CU
+                const int m = mh >> 1, r0 = (mh & 1) * 8;
+                float gc[8], gh[8], gz[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int i = 0; i < 8; ++i) {
+                    const int r = r0 + i;
                     const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
-                    float v = acc[m][n][r] * a.out_scale + bv[m][r];
-                    if (a.relu) v = fmaxf(v, 0.0f);
-                    if (all_co || co_lane + dco < a.Cout) op[dco * iHW] = v;
+                    const bool ok = all_co || co_lane + dco < a.Cout;
+                    const long o = (long)(ok ? dco : 0) * iHW + px;
+                    gc[i] = pc[o];
+                    gh[i] = (a.epi == 2 || second) ? ph[o] : 0.0f;
+                    gz[i] = a.epi == 2 ? pz[o] : 0.0f;
                 }
-        }
-        return;
-    }
-    // ---- fused GRU gates (gru_gates.hip arithmetic with hardware exp/rcp) ----
-    const int Ch = a.epi == 1 ? a.Cout / 2 : a.Cout;
-    const bool second = a.epi == 1 && co_w >= Ch;       // wave-uniform: this wave owns r channels
-    const int cg = co_lane - (second ? Ch : 0);         // channel inside the Ch-wide gate tensors
-    const float *pc = (second ? a.e_c1 : a.e_c0) + (long)b * (second ? a.e_c1_bs : a.e_c0_bs) + (long)cg * HW;
-    const float *pz = a.e_c1 + (long)b * a.e_c1_bs + (long)cg * HW;       // epi 2 only
-    const float *ph = a.e_h + (long)b * a.e_h_bs + (long)cg * HW;
-    float *po = (second ? a.out2 + (long)b * a.out2_bs : a.out + (long)b * a.out_bs) + (long)cg * HW;
 #pragma unroll
-    for (int n = 0; n < NF; ++n) {
-        const int oh = h0 + wn * NF + n, ow = w0 + li;
-        if (oh >= a.H || ow >= a.W) continue;
-        const long px = (long)oh * a.W + ow;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            // all gate operands of these 16 channels are fetched as one batch BEFORE any store
-            // (hout may alias h, so the compiler cannot hoist the loads over stores itself)
-            float gc[16], gh[16], gz[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
-                const bool ok = all_co || co_lane + dco < a.Cout;
-                const long o = (long)(ok ? dco : 0) * iHW + px;
-                gc[r] = pc[o];
-                gh[r] = (a.epi == 2 || second) ? ph[o] : 0.0f;
-                gz[r] = a.epi == 2 ? pz[o] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
-                if (!(all_co || co_lane + dco < a.Cout)) continue;
-                const long o = (long)dco * iHW + px;
-                const float v = acc[m][n][r] * a.out_scale + bv[m][r];
-                if (a.epi == 1) {
-                    const float g = conv_sigmoid(__fadd_rn(v, gc[r]));
-                    po[o] = second ? __fmul_rn(g, gh[r]) : g;
-                } else {
-                    const float q = conv_tanh(__fadd_rn(v, gc[r]));
-                    po[o] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, gz[r]), gh[r]), __fmul_rn(gz[r], q));
+                for (int i = 0; i < 8; ++i) {
+                    const int r = r0 + i;
+                    const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (!(all_co || co_lane + dco < a.Cout)) continue;
+                    const long o = (long)dco * iHW + px;
+                    const float v = acc[m][n][r] * a.out_scale + bv[m][r];
+                    if (a.epi == 1) {
+                        const float g = conv_sigmoid(__fadd_rn(v, gc[i]));
+                        po[o] = second ? __fmul_rn(g, gh[i]) : g;
+                    } else {
+                        const float q = conv_tanh(__fadd_rn(v, gc[i]));
+                        po[o] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, gz[i]), gh[i]), __fmul_rn(gz[i], q));
+                    }
                 }
             }
         }
+    };
+
+    constexpr int HALF = NSTEP / 2;
+    constexpr int PER = (NSL + HALF - 1) / HALF;
+    constexpr int NMMA = 2 * NF * PASSES;
+    stage_tile(h0, w0);
+    stage_select(b, 0);
+    stage_load(0, NSL);
+    stage_store(lds, 0, NSL);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < AR - 1; ++s) loadA(s, wl_cur, 0, s);
+    loadB(0, lds, 0);
+    int g = 0;                               // chunks consumed by this block: LDS buffer parity
+    for (;;) {
+        const int tn = tile + (int)gridDim.x;
+        const bool have_next = tn < a.total_tiles;
+        int nh0 = h0, nw0 = w0, nco = co_blk, nb = b;
+        if (have_next) decode(tn, nh0, nw0, nco, nb);
+        wl_nxt = wlane_of(nco);
+        for (int c = 0; c < nchunks; ++c, ++g) {
+            const bool in_tile = c + 1 < nchunks;
+            const bool more = in_tile || have_next;
+            const unsigned *cur = lds + (g & 1) * STAGE;
+            unsigned *nxt = lds + ((g + 1) & 1) * STAGE;
+            // what this chunk's steps stage and prefetch: the tile's next chunk, else the next
+            // tile's first chunk, else (the block's very last chunk) itself again, harmlessly,
+            // into the idle buffer
+            const int c_f = in_tile ? c + 1 : (have_next ? 0 : c);
+            const long wl_f = in_tile ? wl_cur : wl_nxt;
+            if (in_tile || !have_next) stage_select(b, c_f);
+            else {
+                stage_select(nb, 0);
+                stage_tile(nh0, nw0);
+            }
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                // weights for step s+AR-1 (possibly the following chunk's first steps)
+                const int sa = s + AR - 1;
+                if (!(ABL & 1)) {
+                    if (sa < NSTEP) loadA(sa % AR, wl_cur, c, sa);
+                    else loadA(sa % AR, wl_f, c_f, sa - NSTEP);
+                }
+                if (s + 1 < NSTEP && !(ABL & 2)) loadB((s + 1) & 1, cur, s + 1);
+                if (!(ABL & 4)) {
+                    if (s < HALF) stage_load(s * PER, (s + 1) * PER);
+                    else stage_store(nxt, (s - HALF) * PER, (s - HALF + 1) * PER);
+                }
+                if (!(ABL & 8)) mma(s % AR, s & 1);
+                else {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(Ahi[s % AR][m]), "v"(Alo[s % AR][m]));
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) asm volatile("" ::"v"(Bhi[s & 1][n]), "v"(Blo[s & 1][n]));
+                }
+                if (!(ABL & 16)) {
+#pragma unroll
+                    for (int i = 0; i < NMMA / CONV_SGB_MFMA; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, CONV_SGB_MFMA, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x320, CONV_SGB_MEM, 0);    // VMEM read / DS read / DS write
+                        __builtin_amdgcn_sched_group_barrier(0x002, CONV_SGB_VALU, 0);   // VALU
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            if (more && !(ABL & 2)) loadB(0, nxt, 0);      // NSTEP is even: step 0 always uses B slot 0
+        }
+        epilogue();
+        if (!have_next) break;
+        tile = tn; h0 = nh0; w0 = nw0; co_blk = nco; b = nb;
+        wl_cur = wl_nxt;
+        zero_acc();
     }
 }
 
@@ -462,27 +542,42 @@ extern "C" int dkt_conv2d_pack_weights(const float *w, const int *src_channels, 
     return dkt_launch_status();
 }
 
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = 0>
-static int launch_conv(const ConvArgs &a, int B, hipStream_t st) {
+// Resident blocks the device holds of one instantiation (occupancy x CUs), cached per device.
+static int conv_slots(const void *kern, size_t lds, int dev) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    return per_cu * cus;
+}
+
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL>
+static int launch_conv(ConvArgs a, int B, hipStream_t st) {
     constexpr int HALO = KS / 2;
     constexpr int NPP = (NF * WN + 2 * HALO) * (32 + 2 * HALO);
     constexpr int STAGE = NPP * 20 * (PASSES == 3 ? 2 : 1);
-    const size_t lds = ((size_t)2 * STAGE + 4) * sizeof(unsigned);   // + dummy words for surplus staging items
+    const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);   // + dummy words for surplus staging lanes
     auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL>;
-    if (lds > 64 * 1024) {
-        // once per device and instantiation (and never inside a stream capture after warm-up)
-        static unsigned long long done_mask = 0;       // benign race: worst case it is set twice
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (!(done_mask >> (dev & 63) & 1ull)) {
+    // once per device and instantiation (and never inside a stream capture after warm-up)
+    static int slots[64] = {0};                        // benign race: worst case computed twice
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!slots[dev & 63]) {
+        if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
-            done_mask |= 1ull << (dev & 63);
         }
+        slots[dev & 63] = conv_slots((const void *)kern, lds, dev);
     }
     const int tiles_h = (a.H + NF * WN - 1) / (NF * WN);
-    dim3 grid((unsigned)(a.tiles_w * tiles_h), (unsigned)((a.Cout + 64 * WM - 1) / (64 * WM)), (unsigned)B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    a.tiles_xy = a.tiles_w * tiles_h;
+    a.n_co = (a.Cout + 64 * WM - 1) / (64 * WM);
+    const long total = (long)a.tiles_xy * a.n_co * B;
+    if (total > 0x7fffffffL) return DKT_E_SHAPE;
+    a.total_tiles = (int)total;
+    // DKT_CONV_PERSIST=0 (tuning knob): one block per tile, i.e. no cross-tile pipelining
+    static const bool persist = [] { const char *e = getenv("DKT_CONV_PERSIST"); return !e || atoi(e) != 0; }();
+    const long nblk = persist && total > slots[dev & 63] ? slots[dev & 63] : total;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
     return dkt_launch_status();
 }
 
@@ -493,14 +588,21 @@ static int launch_conv(const ConvArgs &a, int B, hipStream_t st) {
 template <int KS, int PASSES>
 static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     const long tiles4 = (long)a.tiles_w * ((a.H + 3) / 4) * B;    // blocks if a block covers 4 rows
-    if (a.Cout <= 64) {
-        if (tiles4 / 2 >= 256) return launch_conv<KS, 1, 4, 2, PASSES>(a, B, st);   // 64 co x 8 rows
-        return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);                          // 64 co x 4 rows
+    static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5 forces a tile shape
+        const char *e = getenv("DKT_CONV_CFG");
+        return e ? atoi(e) : 0;
+    }();
+    switch (forced) {
+    case 1: return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);
+    case 3: return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);
+    case 5: return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);
+    default: break;
     }
-    if (a.Cout <= 128) {
-        if (tiles4 / 2 >= 256) return launch_conv<KS, 2, 2, 4, PASSES>(a, B, st);   // 128 co x 8 rows
-        return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);                          // 128 co x 4 rows
-    }
+    // 4-row blocks keep the LDS stage at 65 KB, i.e. two blocks per CU; the 8-row forms
+    // (one block per CU) measured 15-35 % slower on every encoder layer (tools/_exp_enc.py).
+    (void)tiles4;
+    if (a.Cout <= 64) return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);            // 64 co x 4 rows
+    if (a.Cout <= 128) return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);           // 128 co x 4 rows
     // wide layers: 256 co x 2 rows per block, two blocks per CU.  (Measured on 384->256 @184x312:
     // 324 us vs 374 us for the 256 co x 4 rows / one-block-per-CU form.)
     return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);                              // 256 co x 2 rows

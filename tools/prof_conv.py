@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one hot-path kernel in isolation a few times (for rocprofv3 --pmc / --kernel-trace).
-usage: prof_conv.py [zr|q|lookup|build] [reps]"""
+usage: prof_conv.py [zr|q|enc|lookup|build] [reps]"""
 import os
 import sys
 
@@ -23,6 +23,12 @@ with torch.no_grad():
         xs = [torch.randn(1, 128, 184, 312, device=dev) for _ in range(3)]
         for _ in range(reps):
             conv.conv2d(xs, layer)
+    elif which == "enc":          # narrow encoder layer: 64->64 3x3 at 368x624
+        conv.set_backend("f16x3")
+        layer = torch.nn.Conv2d(64, 64, 3, padding=1).to(dev)
+        x = torch.randn(1, 64, 368, 624, device=dev)
+        for _ in range(reps):
+            conv.conv2d(x, layer)
     elif which in ("lookup", "build"):
         f1, f2 = (torch.randn(1, 256, 184, 312, device=dev) for _ in range(2))
         blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
