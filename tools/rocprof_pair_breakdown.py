@@ -14,12 +14,24 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--pair", type=int, default=-3, help="index of the corr1d_build dispatch that opens the window")
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--phases", action="store_true", help="split the pair into the GRU loop (corr build .. last "
+                    "iteration) and the rest (upsampling + the next pair's encoders)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
     lo, hi = idx[a.pair], idx[a.pair + 1]
     win = rows[lo:hi]
+    if a.phases:
+        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"]]
+        end = lk[-1] + (lk[-1] - lk[-2])          # the last iteration is as long as the one before it
+        table(win[:end], a.top, "GRU loop (corr build + %d iterations)" % len(lk))
+        table(win[end:], a.top, "upsampling + encoders")
+    else:
+        table(win, a.top, "one steady-state pair")
+
+
+def table(win, top, title):
     t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
     agg = collections.defaultdict(lambda: [0, 0, 1 << 62, 0])
     for r in win:
@@ -37,9 +49,9 @@ def main():
         k[2] = min(k[2], d)
         k[3] = max(k[3], d)
     tot = sum(v[1] for v in agg.values())
-    print("# one steady-state pair: wall %.2f ms, kernel time %.2f ms, %d dispatches" % ((t1 - t0) / 1e6, tot / 1e6, len(win)))
+    print("# %s: wall %.2f ms, kernel time %.2f ms, %d dispatches" % (title, (t1 - t0) / 1e6, tot / 1e6, len(win)))
     print("%-68s %6s %11s %9s %9s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
-    for n, (c, d, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
+    for n, (c, d, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print("%-68s %6d %11.1f %9.2f %9.2f %9.2f %6.2f" % (n, c, d / 1e3, d / c / 1e3, mn / 1e3, mx / 1e3, 100.0 * d / tot))
 
 
