@@ -282,7 +282,7 @@ def main():
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
         # the kernel BASELINE.json's north_star sets the HBM target for
-        "roofline_lookup": {"kernel": "corr1d_lookup4_kernel<4> (dkt_corr1d_lookup)", "bound": "hbm",
+        "roofline_lookup": {"kernel": "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,

@@ -93,6 +93,7 @@ def clear_weight_cache(module):
     that bypass the Parameter's version counter, e.g. ``weight.data.mul_()``)."""
     for m in module.modules():
         m.__dict__.pop("_dkt_packed", None)
+        m.__dict__.pop("_dkt_folded", None)
         if hasattr(m, "_zr_key"):
             m._zr_key = None
 

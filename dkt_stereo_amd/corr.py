@@ -64,7 +64,9 @@ def _lookup(pyramid, coords, radius, w2, skewed=False):
 def _skew_pyramid(pyramid, B, H, W1, W2, out=None):
     """dkt_corr1d_skew: diagonal-major copy of every level (see corr1d_skew.hip)."""
     if out is None:
-        out = [torch.empty_like(p) for p in pyramid]
+        pitch = _ffi.lib().dkt_corr1d_skew_pitch(W1)
+        out = [torch.empty((B * H, W2 >> i, pitch), device=p.device, dtype=torch.float32)
+               for i, p in enumerate(pyramid)]
     rc = _ffi.lib().dkt_corr1d_skew(_ffi.ptr_array(pyramid), _ffi.ptr_array(out), B, H, W1, W2, len(pyramid),
                                     _ffi.device_of(pyramid[0]), _ffi.stream_of(pyramid[0]))
     _ffi.check(rc, "dkt_corr1d_skew")

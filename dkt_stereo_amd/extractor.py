@@ -36,6 +36,56 @@ def norm_act(norm, x, relu):
     return F.relu(y) if relu else y
 
 
+class _Folded:
+    """A convolution with an eval-mode BatchNorm folded into its weights (duck-types the layer
+    argument of conv.conv2d)."""
+
+
+def _tensor_key(t):
+    return None if t is None else (t.data_ptr(), t._version)
+
+
+def _folded(conv, bn):
+    """conv followed by bn (running statistics):  bn(conv(x)) = conv'(x) with
+    w' = w * g, b' = (b - mean) * g + beta, g = gamma / sqrt(var + eps)  (per output channel).
+    Cached on the conv module; rebuilt when any of the tensors is replaced or written."""
+    key = tuple(_tensor_key(t) for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    hit = conv.__dict__.get("_dkt_folded")
+    if hit is not None and hit.key == key:
+        return hit
+    with torch.no_grad():
+        g = torch.rsqrt(bn.running_var.double() + bn.eps)
+        if bn.weight is not None:
+            g = g * bn.weight.double()
+        b = conv.bias.double() if conv.bias is not None else torch.zeros_like(g)
+        b = (b - bn.running_mean.double()) * g
+        if bn.bias is not None:
+            b = b + bn.bias.double()
+        f = _Folded()
+        f.weight = (conv.weight.double() * g.view(-1, 1, 1, 1)).float().contiguous()
+        f.bias = b.float().contiguous()
+    f.padding = conv.padding
+    f.stride = conv.stride
+    f.key = key
+    conv.__dict__["_dkt_folded"] = f
+    return f
+
+
+def conv_norm_act(conv, norm, x, relu):
+    """norm(conv(x)) [+ ReLU].  An eval-mode BatchNorm (cnet: frozen statistics,
+    raft_stereo.py:56-59) is folded into the convolution and the ReLU into its epilogue, which
+    removes two full passes over the activation per layer; other norms go through norm_act."""
+    if (isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats
+            and isinstance(conv, _Conv2d) and _hip_ok(x) and conv.dilation == (1, 1) and conv.groups == 1
+            and not (torch.is_grad_enabled() and conv.weight.requires_grad)):
+        f = _folded(conv, norm)
+        if conv.stride == (1, 1):
+            return conv2d(x, f, relu=relu)
+        y = F.conv2d(x, f.weight, f.bias, stride=conv.stride, padding=conv.padding)
+        return torch.relu_(y) if relu else y
+    return norm_act(norm, conv(x), relu)
+
+
 def add_relu(a, b):
     """relu(a + b), one pass (dkt_add_relu)."""
     if _hip_ok(a) and _hip_ok(b) and a.shape == b.shape and a.is_contiguous() and b.is_contiguous():
@@ -85,10 +135,10 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(_Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        y = norm_act(self.norm1, self.conv1(x), True)
-        y = norm_act(self.norm2, self.conv2(y), True)
+        y = conv_norm_act(self.conv1, self.norm1, x, True)
+        y = conv_norm_act(self.conv2, self.norm2, y, True)
         if self.downsample is not None:
-            x = norm_act(self.norm3, self.downsample[0](x), False)
+            x = conv_norm_act(self.downsample[0], self.norm3, x, False)
         return add_relu(x, y)
 
 
@@ -123,7 +173,7 @@ class _Trunk(nn.Module):
         self.layer3 = _stage(96, 128, norm_fn, 1 + (downsample > 0))
 
     def _trunk(self, x):
-        x = norm_act(self.norm1, self.conv1(x), True)
+        x = conv_norm_act(self.conv1, self.norm1, x, True)
         return self.layer3(self.layer2(self.layer1(x)))
 
 

@@ -78,9 +78,11 @@ int dkt_corr1d_lookup(const float *const *pyr, const float *coords_x, long coord
 
 /* Diagonal-major ("skewed") copy of the pyramid and the lookup that reads it:
  *   skew[i][row][s][w1] = pyr[i][row*W1 + w1][(s + (w1 >> i)) mod (W2>>i)],  row = b*H + h
- * (same sizes as pyr[i]).  Neighbouring pixels with similar disparity then read neighbouring
+ * with the w1 axis padded to dkt_corr1d_skew_pitch(W1) floats (a multiple of 32: every (row, s)
+ * line is 128-byte aligned), i.e. skew[i] holds B*H*(W2>>i)*pitch floats.  Neighbouring pixels with similar disparity then read neighbouring
  * floats: a wave's tap is one contiguous 256-byte load instead of 64 separate lines
  * (corr1d_skew.hip).  dkt_corr1d_lookup_skew returns exactly what dkt_corr1d_lookup does. */
+int dkt_corr1d_skew_pitch(int W1);
 int dkt_corr1d_skew(const float *const *pyr, float *const *skew, int B, int H, int W1, int W2, int L,
                     int device, void *stream);
 int dkt_corr1d_lookup_skew(const float *const *skew, const float *coords_x, long coords_bstride,

@@ -463,8 +463,37 @@ def test_skewed_pyramid_lookup_is_bit_identical(name):
     for i, (p, s) in enumerate(zip(blk.corr_pyramid, blk._skew)):
         wi = c["W2"] >> i
         P = p.view(B * H, W1, wi).cpu()
-        S = s.view(B * H, wi, W1).cpu()
+        S = s.view(B * H, wi, -1)[:, :, :W1].cpu()
         w1 = torch.arange(W1)
         for sv in (0, 1, wi - 1, wi // 2):
             col = (sv + (w1 >> i)) % wi
             assert torch.equal(S[:, sv, :], P[:, w1, col])
+
+
+@pytest.mark.parametrize("W", [312, 77, 640, 1000])
+@torch.no_grad()
+def test_skew_lookup_fast_division_is_exact(W):
+    """dkt_corr1d_lookup_skew evaluates the sampler's 2x/(W-1) with a reciprocal + two fma
+    corrections; dkt_corr1d_lookup uses the IEEE division.  Bit-identical outputs over
+    ~10^8 divisions per width (random, integral, half-integral and out-of-range coordinates,
+    4 pyramid levels = 4 divisors per width)."""
+    from dkt_stereo_amd.corr import CorrBlock1D, _lookup
+    H, C = 48, 8
+    g = torch.Generator(device=DEV).manual_seed(1000 + W)
+    f1 = torch.randn(1, C, H, W, device=DEV, generator=g)
+    f2 = torch.randn(1, C, H, W, device=DEV, generator=g)
+    blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+    assert blk._skew is not None
+    base = torch.arange(W, device=DEV, dtype=torch.float32).view(1, 1, 1, W).expand(1, 1, H, W)
+    for rep in range(24):
+        r = torch.rand(1, 1, H, W, device=DEV, generator=g)
+        if rep % 4 == 0:
+            x = base - (r * 64).floor()                         # integral
+        elif rep % 4 == 1:
+            x = base - (r * 128).floor() * 0.5                  # half-integral
+        elif rep % 4 == 2:
+            x = (r * (W + 40) - 20)                             # anywhere, incl. out of range
+        else:
+            x = base - r * 60 * (1 + rep)                       # smooth-ish, far left for large rep
+        coords = torch.cat([x, torch.zeros_like(x)], 1).contiguous()
+        assert torch.equal(blk(coords), _lookup(blk.corr_pyramid, coords, 4, W))
