@@ -197,6 +197,17 @@ def interp(x, dest):
     return y
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
+
+
 class BasicMultiUpdateBlock(nn.Module):
     """core/update.py:97-138 (RAFT-Stereo).  ``forward`` keeps the reference's
     signature and, like it, updates the caller's ``net`` list in place.
@@ -224,10 +235,23 @@ class BasicMultiUpdateBlock(nn.Module):
     #: harness switch: GRUs overwrite their hidden-state tensors instead of allocating new ones
     #: (the reference rebinds net[i] to a fresh tensor; nothing else may hold the old one)
     inplace_state = False
+    #: run the motion encoder concurrently with gru32/gru16 on a second stream (DKT_SIDE_STREAM=0 disables)
+    side_stream = os.environ.get("DKT_SIDE_STREAM", "1") != "0"
 
     def _gru_stack(self, net, inp, fine, mid, coarse, motion, it_fine, it_mid, it_coarse):
         n = self.args.n_gru_layers
         o = (lambda t: t) if self.inplace_state else (lambda t: None)
+        # The motion encoder (5 convolutions of the finest scale) does not depend on the two
+        # coarse GRUs, whose small images leave most CUs idle (gru16: 115 tiles, gru32: 69, for
+        # 512 resident blocks): it runs on a second HIP stream beside them and joins before
+        # gru08.  Inside the captured iteration graph this is a parallel branch.
+        side = main = None
+        if it_fine and (it_coarse or it_mid) and self.side_stream and net[0].is_cuda:
+            main = torch.cuda.current_stream(net[0].device)
+            side = _side_stream(net[0].device)
+            side.wait_stream(main)              # fork
+            with torch.cuda.stream(side):
+                mf = motion()
         if it_coarse:
             net[2] = coarse(net[2], *(inp[2]), pool2x(net[1]), out=o(net[2]))
         if it_mid:
@@ -236,7 +260,10 @@ class BasicMultiUpdateBlock(nn.Module):
             else:
                 net[1] = mid(net[1], *(inp[1]), pool2x(net[0]), out=o(net[1]))
         if it_fine:
-            mf = motion()
+            if side is not None:
+                main.wait_stream(side)          # join: gru08 consumes the motion features
+            else:
+                mf = motion()
             if n > 1:
                 net[0] = fine(net[0], *(inp[0]), mf, interp(net[1], net[0]), out=o(net[0]))
             else:
