@@ -588,7 +588,7 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
 template <int KS, int PASSES>
 static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     const long tiles4 = (long)a.tiles_w * ((a.H + 3) / 4) * B;    // blocks if a block covers 4 rows
-    static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5 forces a tile shape
+    static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5|6|7 forces a tile shape
         const char *e = getenv("DKT_CONV_CFG");
         return e ? atoi(e) : 0;
     }();
@@ -596,13 +596,23 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     case 1: return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);
     case 3: return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);
     case 5: return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);
+    case 6: return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);
+    case 7: return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);
     default: break;
     }
     // 4-row blocks keep the LDS stage at 65 KB, i.e. two blocks per CU; the 8-row forms
     // (one block per CU) measured 15-35 % slower on every encoder layer (tools/_exp_enc.py).
+    // Small images (the 1/8 and 1/16 GRUs: 115 and 69 tiles of the default shape for 256 CUs)
+    // take half-height tiles so that twice as many CUs work.
     (void)tiles4;
+    const long few = 200;
     if (a.Cout <= 64) return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);            // 64 co x 4 rows
-    if (a.Cout <= 128) return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);           // 128 co x 4 rows
+    if (a.Cout <= 128) {
+        if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);        // 128 co x 2 rows
+        return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);                          // 128 co x 4 rows
+    }
+    const long tiles2 = (long)a.tiles_w * ((a.H + 1) / 2) * B * ((a.Cout + 255) / 256);
+    if (tiles2 < few) return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);            // 256 co x 1 row
     // wide layers: 256 co x 2 rows per block, two blocks per CU.  (Measured on 384->256 @184x312:
     // 324 us vs 374 us for the 256 co x 4 rows / one-block-per-CU form.)
     return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);                              // 256 co x 2 rows

@@ -83,13 +83,16 @@ def test_direct_conv_vs_fp64(shape):
     from dkt_stereo_amd import conv
     name, B, cin, cout, H, W, k, relu = shape
     conv.set_backend("f16x3")
+    torch.manual_seed(1234)
     layer = torch.nn.Conv2d(cin, cout, k, padding=k // 2).to(DEV)
     assert conv.direct_eligible(layer) == (k == 7)
     x = G(_synth.normal((B, cin, H, W), 95, name, scale=2.0))
     ref = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=k // 2)
     ref = ref.clamp_min(0) if relu else ref
     got = conv._conv2d_direct(x, layer, relu, None)
-    assert float((got.double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    # sequential fp32 FMAs over K = cin*k*k terms: round-off grows like sqrt(K) * 2^-24
+    tol = max(2e-6, 1.5e-7 * (cin * k * k) ** 0.5)
+    assert float((got.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
 @torch.no_grad()
