@@ -12,6 +12,7 @@ is not present.
 call convention (tools/evaluate_stereo.py:129).  Only ``test_mode=True`` is
 implemented: the HIP operators are inference-only.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -21,7 +22,7 @@ import torch.nn.functional as F
 from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
 from .extractor import BasicEncoder, MultiBasicEncoder
-from .update import BasicMultiUpdateBlock
+from .update import BasicMultiUpdateBlock, _side_stream
 from .utils import coords_grid
 
 #: configs/raft_stereo/base.json of the reference
@@ -58,14 +59,28 @@ class RAFTStereo(nn.Module):
             if isinstance(m, nn.BatchNorm2d):
                 m.eval()
 
+    #: run fnet and cnet on two HIP streams (DKT_ENCODER_STREAMS=0 disables)
+    encoder_streams = os.environ.get("DKT_ENCODER_STREAMS", "1") != "0"
+
     # -- pieces of the reference forward, split so the hot path can be timed alone --
     def encode(self, image1, image2):
         """raft_stereo.py:91-116: normalisation, encoders, context split."""
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         n = self.args.n_gru_layers
-        cnet_list = self.cnet(image1, num_layers=n)
-        fmap1, fmap2 = self.fnet([image1, image2])
+        if self.encoder_streams and image1.is_cuda:
+            # the two encoders are independent: fnet runs on a second stream beside cnet (the
+            # small layers of either one leave CUs idle); joined before anything consumes fmaps
+            main = torch.cuda.current_stream(image1.device)
+            side = _side_stream(image1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fmap1, fmap2 = self.fnet([image1, image2])
+            cnet_list = self.cnet(image1, num_layers=n)
+            main.wait_stream(side)
+        else:
+            cnet_list = self.cnet(image1, num_layers=n)
+            fmap1, fmap2 = self.fnet([image1, image2])
         net_list = [torch.tanh(x[0]) for x in cnet_list]
         inp_list = [torch.relu(x[1]) for x in cnet_list]
         inp_list = [list(conv2d(i, conv).split(split_size=conv.out_channels // 3, dim=1))
