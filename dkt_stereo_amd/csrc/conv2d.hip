@@ -49,6 +49,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CONV_MIN_BLOCKS
 #define CONV_MIN_BLOCKS 2    // blocks per CU the register budget is capped for (256 VGPRs)
 #endif
+#ifndef CONV_FEW_TILES
+#define CONV_FEW_TILES 200   // fewer tiles than this: half-height tile shapes
+#endif
 #ifndef CONV_AR_NF1
 #define CONV_AR_NF1 3
 #endif
@@ -605,7 +608,7 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     // Small images (the 1/8 and 1/16 GRUs: 115 and 69 tiles of the default shape for 256 CUs)
     // take half-height tiles so that twice as many CUs work.
     (void)tiles4;
-    const long few = 200;
+    const long few = CONV_FEW_TILES;
     if (a.Cout <= 64) return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);            // 64 co x 4 rows
     if (a.Cout <= 128) {
         if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);        // 128 co x 2 rows

@@ -140,25 +140,46 @@ extern "C" int dkt_add_relu(const float *a, const float *b, float *y, long n, in
 // avg_pool2d(x, 3, stride=2, padding=1), count_include_pad=True (divide by 9 always).
 // Sum order: rows top to bottom, columns left to right (ATen's loop order), then * (1/9)?
 // ATen divides the sum by the pool size: sum / 9.
+// One thread = 4 adjacent outputs of one row (one float4 store when Wo % 4 == 0): the 9 input
+// columns they share are read once per input row instead of 12 times.
 __global__ __launch_bounds__(256) void pool2x_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                      int H, int W, int Ho, int Wo, long planes) {
-    const long total = planes * Ho * Wo;
+    const int Wq = (Wo + 3) / 4;
+    const long total = planes * Ho * Wq;
+    const bool vec = (Wo & 3) == 0 && (((uintptr_t)y) & 15) == 0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ox = (int)(i % Wo);
-        const int oy = (int)((i / Wo) % Ho);
-        const long pl = i / ((long)Wo * Ho);
+        const int oq = (int)(i % Wq);
+        const int oy = (int)((i / Wq) % Ho);
+        const long pl = i / ((long)Wq * Ho);
         const float *p = x + pl * H * W;
-        float s = 0.0f;
+        const int ox0 = 4 * oq;
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int iy = 2 * oy - 1 + dy;
+            if (iy < 0 || iy >= H) continue;
+            float v[9];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ix = 2 * ox - 1 + dx;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) s = __fadd_rn(s, p[(long)iy * W + ix]);
+            for (int j = 0; j < 9; ++j) {
+                const int ix = 2 * ox0 - 1 + j;
+                v[j] = (ix >= 0 && ix < W) ? p[(long)iy * W + ix] : 0.0f;      // adding +0.0f leaves the sum unchanged
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int ix = 2 * (ox0 + k) - 1 + dx;
+                    if (ix >= 0 && ix < W) s[k] = __fadd_rn(s[k], v[2 * k + dx]);
+                }
         }
-        y[i] = __fdiv_rn(s, 9.0f);
+        float *q = y + (pl * Ho + oy) * (long)Wo + ox0;
+        if (vec) {
+            *(float4 *)q = make_float4(__fdiv_rn(s[0], 9.0f), __fdiv_rn(s[1], 9.0f), __fdiv_rn(s[2], 9.0f), __fdiv_rn(s[3], 9.0f));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ox0 + k < Wo) q[k] = __fdiv_rn(s[k], 9.0f);
+        }
     }
 }
 
@@ -167,8 +188,8 @@ extern "C" int dkt_pool2x(const float *x, float *y, long planes, int H, int W, i
     if (planes <= 0 || H <= 0 || W <= 0) return DKT_E_SHAPE;
     DKT_ENTER(device);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    long blocks = (planes * Ho * Wo + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    long blocks = (planes * Ho * ((Wo + 3) / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        x, y, H, W, Ho, Wo, planes);
     return dkt_launch_status();
@@ -177,24 +198,45 @@ extern "C" int dkt_pool2x(const float *x, float *y, long planes, int H, int W, i
 // F.interpolate(x, (Ho,Wo), mode='bilinear', align_corners=True): ATen's
 //   src = dst * (in-1)/(out-1);  i0 = (int)src;  l1 = src - i0;  l0 = 1 - l1
 //   out = l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
+// One thread = 4 adjacent outputs of one row (float4 store when Wo % 4 == 0); the row weights
+// and the two source-row pointers are shared by the four.
 __global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                      int H, int W, int Ho, int Wo, float sy, float sx, long planes) {
-    const long total = planes * Ho * Wo;
+    const int Wq = (Wo + 3) / 4;
+    const long total = planes * Ho * Wq;
+    const bool vec = (Wo & 3) == 0 && (((uintptr_t)y) & 15) == 0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ox = (int)(i % Wo);
-        const int oy = (int)((i / Wo) % Ho);
-        const long pl = i / ((long)Wo * Ho);
+        const int oq = (int)(i % Wq);
+        const int oy = (int)((i / Wq) % Ho);
+        const long pl = i / ((long)Wq * Ho);
         const float *p = x + pl * H * W;
-        const float fy = __fmul_rn(sy, (float)oy), fx = __fmul_rn(sx, (float)ox);
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-        const float ly1 = __fsub_rn(fy, (float)y0), lx1 = __fsub_rn(fx, (float)x0);
-        const float ly0 = __fsub_rn(1.0f, ly1), lx0 = __fsub_rn(1.0f, lx1);
-        const float v00 = p[(long)y0 * W + x0], v01 = p[(long)y0 * W + x1];
-        const float v10 = p[(long)y1 * W + x0], v11 = p[(long)y1 * W + x1];
-        const float top = __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01));
-        const float bot = __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11));
-        y[i] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+        const float fy = __fmul_rn(sy, (float)oy);
+        const int y0 = (int)fy;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+        const float ly1 = __fsub_rn(fy, (float)y0);
+        const float ly0 = __fsub_rn(1.0f, ly1);
+        const float *r0 = p + (long)y0 * W, *r1 = p + (long)y1 * W;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ox = min(4 * oq + k, Wo - 1);
+            const float fx = __fmul_rn(sx, (float)ox);
+            const int x0 = (int)fx;
+            const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float lx1 = __fsub_rn(fx, (float)x0);
+            const float lx0 = __fsub_rn(1.0f, lx1);
+            const float top = __fadd_rn(__fmul_rn(lx0, r0[x0]), __fmul_rn(lx1, r0[x1]));
+            const float bot = __fadd_rn(__fmul_rn(lx0, r1[x0]), __fmul_rn(lx1, r1[x1]));
+            o[k] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+        }
+        float *q = y + (pl * Ho + oy) * (long)Wo + 4 * oq;
+        if (vec) {
+            *(float4 *)q = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * oq + k < Wo) q[k] = o[k];
+        }
     }
 }
 
@@ -205,8 +247,8 @@ extern "C" int dkt_interp_bilinear(const float *x, float *y, long planes, int H,
     DKT_ENTER(device);
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.0f;
     const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.0f;
-    long blocks = (planes * Ho * Wo + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    long blocks = (planes * Ho * ((Wo + 3) / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(interp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        x, y, H, W, Ho, Wo, sy, sx, planes);
     return dkt_launch_status();
