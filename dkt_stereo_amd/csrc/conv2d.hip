@@ -27,10 +27,10 @@
 //       block (a block spans up to 256 output channels, so a patch is staged once);
 //   D accumulators keep pixels along lanes (C/D map col = l&31), so output
 //       stores are 128-byte NCHW rows.
-// Block = 4 waves, one per SIMD (the kernel wants the whole register file: up to
-// 128 accumulators + three weight-fragment sets in flight).  Wave tile = 64 output
-// channels x NF rows x 32 columns; WM x WN waves along (channels, rows).  LDS is
-// double buffered: the fp32 loads of chunk c+1 are in flight under the MFMAs of
+// Block = 4 waves inside a 256-VGPR budget (two blocks per CU).  Wave tile = 64 output
+// channels x NF rows x 32 columns; WM x WN waves along (channels, rows).  Blocks are
+// persistent (a stream of tiles per block); LDS is double buffered: the fp32 loads of
+// chunk c+1 -- of this tile or the block's next one -- are in flight under the MFMAs of
 // chunk c; one barrier per chunk.
 #include "dkt_common.h"
 #include <cstdlib>

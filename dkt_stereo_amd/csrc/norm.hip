@@ -140,46 +140,25 @@ extern "C" int dkt_add_relu(const float *a, const float *b, float *y, long n, in
 // avg_pool2d(x, 3, stride=2, padding=1), count_include_pad=True (divide by 9 always).
 // Sum order: rows top to bottom, columns left to right (ATen's loop order), then * (1/9)?
 // ATen divides the sum by the pool size: sum / 9.
-// One thread = 4 adjacent outputs of one row (one float4 store when Wo % 4 == 0): the 9 input
-// columns they share are read once per input row instead of 12 times.
 __global__ __launch_bounds__(256) void pool2x_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                      int H, int W, int Ho, int Wo, long planes) {
-    const int Wq = (Wo + 3) / 4;
-    const long total = planes * Ho * Wq;
-    const bool vec = (Wo & 3) == 0 && (((uintptr_t)y) & 15) == 0;
+    const long total = planes * Ho * Wo;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int oq = (int)(i % Wq);
-        const int oy = (int)((i / Wq) % Ho);
-        const long pl = i / ((long)Wq * Ho);
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const long pl = i / ((long)Wo * Ho);
         const float *p = x + pl * H * W;
-        const int ox0 = 4 * oq;
-        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float s = 0.0f;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int iy = 2 * oy - 1 + dy;
-            if (iy < 0 || iy >= H) continue;
-            float v[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int ix = 2 * ox0 - 1 + j;
-                v[j] = (ix >= 0 && ix < W) ? p[(long)iy * W + ix] : 0.0f;      // adding +0.0f leaves the sum unchanged
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox - 1 + dx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) s = __fadd_rn(s, p[(long)iy * W + ix]);
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int ix = 2 * (ox0 + k) - 1 + dx;
-                    if (ix >= 0 && ix < W) s[k] = __fadd_rn(s[k], v[2 * k + dx]);
-                }
         }
-        float *q = y + (pl * Ho + oy) * (long)Wo + ox0;
-        if (vec) {
-            *(float4 *)q = make_float4(__fdiv_rn(s[0], 9.0f), __fdiv_rn(s[1], 9.0f), __fdiv_rn(s[2], 9.0f), __fdiv_rn(s[3], 9.0f));
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (ox0 + k < Wo) q[k] = __fdiv_rn(s[k], 9.0f);
-        }
+        y[i] = __fdiv_rn(s, 9.0f);
     }
 }
 
@@ -188,8 +167,8 @@ extern "C" int dkt_pool2x(const float *x, float *y, long planes, int H, int W, i
     if (planes <= 0 || H <= 0 || W <= 0) return DKT_E_SHAPE;
     DKT_ENTER(device);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    long blocks = (planes * Ho * ((Wo + 3) / 4) + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    long blocks = (planes * Ho * Wo + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        x, y, H, W, Ho, Wo, planes);
     return dkt_launch_status();
