@@ -79,6 +79,35 @@ def build_gwc_concat_volume(gwc_ref, gwc_tgt, cat_ref, cat_tgt, maxdisp, num_gro
     return vol
 
 
+def _group_l2norm(x, num_groups):
+    """x / (||x||_2 per channel group + 1e-05): meta_arch/cgi/submodule.py:149,168."""
+    _ffi.require_gpu(x)
+    _ffi.require_no_grad(x)
+    x = x.float().contiguous()
+    B, C, H, W = x.shape
+    if C % num_groups != 0:
+        raise AssertionError("C %% num_groups != 0")          # the reference asserts (submodule.py:145)
+    y = torch.empty_like(x)
+    rc = _ffi.lib().dkt_group_l2norm(x.data_ptr(), y.data_ptr(), B, C, H * W, num_groups, 1e-05,
+                                     _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_group_l2norm")
+    return y
+
+
+def build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """meta_arch/cgi/submodule.py:154-164: group-wise correlation of features normalised per
+    channel group.  The norm reduces over channels only, so normalising the two maps once and
+    running the plain group-wise volume is the same computation as the reference's per-
+    disparity slices."""
+    return build_gwc_volume(_group_l2norm(refimg_fea, num_groups), _group_l2norm(targetimg_fea, num_groups),
+                            maxdisp, num_groups)
+
+
+def build_norm_correlation_volume(refimg_fea, targetimg_fea, maxdisp):
+    """meta_arch/cgi/submodule.py:171-180 (== igev_stereo/submodule.py:179): (B,1,D,H,W)."""
+    return build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, 1)
+
+
 def disparity_regression(x, maxdisp):
     """igev_stereo/submodule.py:220-224 (keepdim=True flavour)."""
     assert len(x.shape) == 4

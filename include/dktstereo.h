@@ -107,6 +107,27 @@ int dkt_pool_w(const float *src, float *dst, long rows, int W, int device, void 
 int dkt_l2norm_channels(const float *src, float *dst, int B, int C, long HW,
                         int device, void *stream);
 
+/* ---- PCVNet correlation block / CGI normalised correlation -------- */
+
+/* F.avg_pool2d(x,[1,factor],stride=[1,factor]) on rows: src (rows,W) -> dst (rows,W/factor);
+ * the pyramid of meta_arch/pcvnet/corr.py:27-31 (factor 4 when n_downsample == 2, else 2). */
+int dkt_pool_rows(const float *src, float *dst, long rows, int W, int factor, int device, void *stream);
+
+/* PCVNet CorrBlock1D.__call__(coords, sigma), meta_arch/pcvnet/corr.py:33-51.
+ * pyr: HOST array of L device pointers, level i (B*H*W1, W_i), W_0 = W2, W_{i+1} = W_i/factor.
+ * coords, sigma: (B,G,H,W1).  out: (B, L*G*S, H, W1), channel = level*G*S + g*S + s,
+ * sampled at (dx_s * sigma + coords) / factor^level, dx = -(S/2)..(S/2) (S odd). */
+int dkt_pcv_lookup(const float *const *pyr, const float *coords, const float *sigma, float *out,
+                   int B, int G, int H, int W1, int W2, int L, int S, int factor,
+                   int device, void *stream);
+
+/* y = x / (||x||_2 over each of G contiguous channel groups + eps): the normalisation inside
+ * groupwise_correlation_norm / norm_correlation, meta_arch/cgi/submodule.py:149,168 (eps 1e-5).
+ * build_gwc_volume_norm(ref,tgt,D,G) = dkt_gwc_volume on the two normalised maps;
+ * build_norm_correlation_volume is G = 1. */
+int dkt_group_l2norm(const float *x, float *y, int B, int C, long HW, int G, float eps,
+                     int device, void *stream);
+
 /* ---- IGEV combined geometry encoding volume ------------------------------ */
 
 /* Pairwise mean along D of a (B*C, D, HW) volume -> (B*C, D/2, HW): the

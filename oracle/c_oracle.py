@@ -169,3 +169,38 @@ def conv2d_same(x, w, bias):
     bp = _p(_c(bias)) if bias is not None else None
     lib().orc_conv2d_same(_p(x), _p(w), bp, _p(y), B, Cin, H, W, Cout, KH, KW)
     return y
+
+
+def pcv_pyramid(lvl0, num_levels, factor):
+    """Rows pooled by `factor` (meta_arch/pcvnet/corr.py:27-31): list of num_levels (N, W_i)."""
+    out = [_c(lvl0)]
+    for _ in range(num_levels - 1):
+        src = out[-1]
+        dst = np.empty((src.shape[0], src.shape[1] // factor), np.float32)
+        lib().orc_pool_rows_f(_p(src), _p(dst), ctypes.c_size_t(src.shape[0]), src.shape[1], factor)
+        out.append(dst)
+    return out
+
+
+def pcv_lookup(pyr, coords, sigma, sample_num, factor):
+    """meta_arch/pcvnet/corr.py:33-51 on a given pyramid; coords, sigma: (B,G,H,W1)."""
+    coords, sigma = _c(coords), _c(sigma)
+    B, G, H, W1 = coords.shape
+    pyr = [_c(p) for p in pyr]
+    L = len(pyr)
+    out = np.empty((B, L * G * sample_num, H, W1), np.float32)
+    lib().orc_pcv_lookup(_pp(pyr), _p(coords), _p(sigma), _p(out), B, G, H, W1, pyr[0].shape[1], L, sample_num, factor)
+    return out
+
+
+def group_l2norm(x, num_groups):
+    x = _c(x)
+    B, C, H, W = x.shape
+    y = np.empty_like(x)
+    lib().orc_group_l2norm(_p(x), _p(y), B, C, H, W, num_groups)
+    return y
+
+
+def gwc_volume_norm(ref, tgt, maxdisp, num_groups):
+    """cgi/submodule.py:143-164 (num_groups=1: build_norm_correlation_volume, :167-180)."""
+    return gwc_volume(group_l2norm(ref, num_groups), group_l2norm(tgt, num_groups), maxdisp, num_groups)

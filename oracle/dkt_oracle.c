@@ -405,4 +405,85 @@ void orc_conv2d_same(const float *x, const float *w, const float *bias, float *y
                 }
 }
 
-int orc_version(void) { return 1; }
+
+/* ------------------------------------------------------------------------
+ * PCVNet correlation block: meta_arch/pcvnet/corr.py:18-61.
+ * Pyramid (corr.py:27-31): level i+1 = F.avg_pool2d(level i, [1,f], stride=[1,f]) with
+ * f = compress_factor (4 when n_downsample == 2, else 2): the window is summed left to
+ * right and divided by f, floor on widths that f does not divide.  All num_levels levels
+ * are used (unlike core/corr.py there is no surplus level).
+ * ---------------------------------------------------------------------- */
+void orc_pool_rows_f(const float *src, float *dst, size_t rows, int W, int f)
+{
+    const int wo = W / f;
+    for (size_t n = 0; n < rows; ++n)
+        for (int k = 0; k < wo; ++k) {
+            float s = 0.0f;
+            for (int j = 0; j < f; ++j)
+                s += src[n * (size_t)W + (size_t)k * f + j];
+            dst[n * (size_t)wo + k] = s / (float)f;
+        }
+}
+
+/* __call__(coords, sigma): corr.py:33-51.  coords, sigma: (B,G,H,W1) (G gaussians per pixel);
+ *   x = dx*sigma + coords,  dx = -(S/2)..(S/2)  (torch.range, S samples; product and sum are
+ *   two separate roundings);  level i samples at x / f^i;
+ *   out[b, i*G*S + g*S + s, h, w1] = sample(pyr[i][n,:], x / f^i)
+ * with the sampler of pcvnet/utils/utils.py:59-74 (same function as core/utils/utils.py). */
+void orc_pcv_lookup(const float *const *pyr, const float *coords, const float *sigma, float *out,
+                    int B, int G, int H, int W1, int W2, int L, int S, int f)
+{
+    const size_t HW = (size_t)H * W1;
+    for (int b = 0; b < B; ++b)
+        for (size_t p = 0; p < HW; ++p) {
+            const size_t n = (size_t)b * HW + p;
+            int wi = W2;
+            float div = 1.0f;
+            for (int i = 0; i < L; ++i) {
+                const float *row = pyr[i] + n * (size_t)wi;
+                for (int g = 0; g < G; ++g) {
+                    const float c = coords[((size_t)b * G + g) * HW + p];
+                    const float sg = sigma[((size_t)b * G + g) * HW + p];
+                    for (int s = 0; s < S; ++s) {
+                        const float dx = (float)(s - S / 2);
+                        const float prod = dx * sg;
+                        const float x = prod + c;
+                        out[((size_t)b * L * G * S + (size_t)i * G * S + (size_t)g * S + s) * HW + p] =
+                            orc_sample_row(row, wi, x / div);
+                    }
+                }
+                wi /= f;
+                div *= (float)f;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------
+ * CGI normalised correlation: meta_arch/cgi/submodule.py:143-180
+ * (build_norm_correlation_volume is also igev_stereo/submodule.py:179).
+ *   xn[b,c,h,w] = x[b,c,h,w] / (||x[b, group(c), h, w]||_2 + 1e-05)
+ *   vol[b,g,d,h,w] = mean_{c in g} refn[b,c,h,w] * tgtn[b,c,h,w-d]   (w >= d) else 0
+ * norm_correlation is the single-group case.  The norm of a width-sliced tensor equals the
+ * slice of the norm (it reduces over channels only), so normalising once up front is the
+ * same computation.  Sum of squares: sequential fp32 (torch.norm's order is unspecified).
+ * ---------------------------------------------------------------------- */
+void orc_group_l2norm(const float *x, float *y, int B, int C, int H, int W, int G)
+{
+    const int cpg = C / G;
+    const size_t HW = (size_t)H * W;
+    for (int b = 0; b < B; ++b)
+        for (int g = 0; g < G; ++g)
+            for (size_t p = 0; p < HW; ++p) {
+                const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW + p;
+                float s = 0.0f;
+                for (int j = 0; j < cpg; ++j) {
+                    const float v = x[base + (size_t)j * HW];
+                    s += v * v;
+                }
+                const float d = sqrtf(s) + 1e-05f;
+                for (int j = 0; j < cpg; ++j)
+                    y[base + (size_t)j * HW] = x[base + (size_t)j * HW] / d;
+            }
+}
+
+int orc_version(void) { return 2; }

@@ -412,3 +412,75 @@ def epe(a, b):
 
 def fan_out_std(shape):
     return math.sqrt(2.0 / (shape[0] * shape[2] * shape[3]))
+
+
+# --------------------------------------------------------------------------
+# PCVNet correlation block: meta_arch/pcvnet/corr.py:18-61
+# --------------------------------------------------------------------------
+def pcv_pyramid(fmap1, fmap2, num_levels, downsample=2):
+    """corr.py:19-31: all-pairs volume (scaled by 1/sqrt(C)) and num_levels-1 poolings by the
+    compress factor (4 when downsample == 2, else 2)."""
+    factor = 4 if downsample == 2 else 2
+    vol = corr1d_volume(fmap1, fmap2)
+    b, h, w1, _, w2 = vol.shape
+    lvl = vol.reshape(b * h * w1, 1, 1, w2)
+    pyr = [lvl]
+    for _ in range(num_levels - 1):
+        lvl = F.avg_pool2d(lvl, [1, factor], stride=[1, factor])
+        pyr.append(lvl)
+    return pyr, factor
+
+
+def pcv_lookup(pyr, coords, sigma, sample_num, factor):
+    """corr.py:33-51.  coords, sigma (B,G,H,W) -> (B, L*G*S, H, W)."""
+    b, g, h, w = coords.shape
+    n = b * h * w
+    sg = sigma.permute(0, 2, 3, 1).contiguous().reshape(n, 1, g, 1)
+    cx = coords.permute(0, 2, 3, 1).contiguous().reshape(n, 1, g, 1)
+    half = sample_num // 2
+    dx = torch.arange(-half, half + 1, dtype=torch.float32).view(1, 1, 1, sample_num)
+    x = dx * sg + cx
+    outs = []
+    for i, lvl in enumerate(pyr):
+        x0 = (x / factor ** i).reshape(n, 1, g * sample_num, 1)
+        outs.append(_sample_rows(lvl.contiguous(), x0.contiguous()).view(b, h, w, -1))
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
+# --------------------------------------------------------------------------
+# CGI normalised correlation volumes: meta_arch/cgi/submodule.py:143-180
+# --------------------------------------------------------------------------
+def _group_norm_corr(a, b, groups):
+    bs, c, h, w = a.shape
+    a = a.view(bs, groups, c // groups, h, w)
+    b = b.view(bs, groups, c // groups, h, w)
+    a = a / (torch.norm(a, 2, 2, True) + 1e-05)
+    b = b / (torch.norm(b, 2, 2, True) + 1e-05)
+    return (a * b).mean(dim=2)
+
+
+def gwc_volume_norm(ref, tgt, maxdisp, groups):
+    """build_gwc_volume_norm, submodule.py:154-164."""
+    bs, c, h, w = ref.shape
+    vol = ref.new_zeros(bs, groups, maxdisp, h, w)
+    for d in range(maxdisp):
+        if d == 0:
+            vol[:, :, 0] = _group_norm_corr(ref, tgt, groups)
+        else:
+            vol[:, :, d, :, d:] = _group_norm_corr(ref[..., d:], tgt[..., :-d], groups)
+    return vol.contiguous()
+
+
+def norm_correlation_volume(ref, tgt, maxdisp):
+    """build_norm_correlation_volume, submodule.py:167-180 (== igev_stereo/submodule.py:179)."""
+    def nc(a, b):
+        return torch.mean((a / (torch.norm(a, 2, 1, True) + 1e-05)) * (b / (torch.norm(b, 2, 1, True) + 1e-05)),
+                          dim=1, keepdim=True)
+    bs, c, h, w = ref.shape
+    vol = ref.new_zeros(bs, 1, maxdisp, h, w)
+    for d in range(maxdisp):
+        if d == 0:
+            vol[:, :, 0] = nc(ref, tgt)
+        else:
+            vol[:, :, d, :, d:] = nc(ref[..., d:], tgt[..., :-d])
+    return vol.contiguous()

@@ -41,6 +41,33 @@ def geo_inputs(c):
     return m1, m2, geo, disp, coords
 
 
+# ---- PCVNet correlation block (meta_arch/pcvnet/corr.py) -----------------------
+PCV_CASES = {
+    "ds2":   dict(seed=81, B=1, C=16, H=3, W=64, L=3, S=9, G=2, downsample=2),    # factor 4
+    "ds3":   dict(seed=82, B=2, C=8, H=2, W=40, L=4, S=5, G=3, downsample=3),     # factor 2
+    "odd":   dict(seed=83, B=1, C=12, H=2, W=77, L=3, S=9, G=1, downsample=2),    # widths 77, 19, 4
+}
+
+
+def pcv_inputs(c):
+    f1, f2 = _synth.fmap_pair(c["seed"], c["B"], c["C"], c["H"], c["W"])
+    base = np.arange(c["W"], dtype=np.float32).reshape(1, 1, 1, c["W"])
+    shp = (c["B"], c["G"], c["H"], c["W"])
+    coords = (base - _synth.uniform(shp, 0.0, 0.6 * c["W"], c["seed"], "pcvc")).astype(np.float32)
+    coords[..., 0::7] = np.round(coords[..., 0::7])
+    sigma = _synth.uniform(shp, 0.25, 3.0, c["seed"], "pcvs")
+    sigma[..., 0::5] = 1.0
+    return f1, f2, coords, sigma
+
+
+# ---- CGI normalised correlation volumes (meta_arch/cgi/submodule.py:143-180) --------
+NORMCORR_CASES = {
+    "cgi":  dict(seed=91, B=2, C=12, H=3, W=24, D=8, G=1),
+    "g4":   dict(seed=92, B=1, C=32, H=2, W=30, D=12, G=4),
+    "dgtw": dict(seed=93, B=1, C=6, H=2, W=5, D=7, G=2),
+}
+
+
 # ---- cost volumes ----------------------------------------------------------------
 GWC_CASES = {
     "igev":  dict(seed=31, B=2, C=96, H=3, W=24, D=8, G=8),      # cpg 12

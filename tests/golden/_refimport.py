@@ -31,7 +31,8 @@ def setup():
             for k, v in attrs.items():
                 setattr(m, k, v)
             sys.modules[name] = m
-    for pkg in ("meta_arch", "meta_arch.raft_stereo", "meta_arch.igev_stereo", "meta_arch.gwcnet"):
+    for pkg in ("meta_arch", "meta_arch.raft_stereo", "meta_arch.igev_stereo", "meta_arch.gwcnet",
+                "meta_arch.pcvnet", "meta_arch.pcvnet.utils", "meta_arch.cgi"):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = [os.path.join(REF, *pkg.split("."))]
@@ -50,6 +51,13 @@ def load():
     import meta_arch.igev_stereo.update as iupdate
     import meta_arch.igev_stereo.submodule as isub
     import meta_arch.gwcnet.submodules as gsub
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import meta_arch.pcvnet.corr as pcorr
+        import meta_arch.cgi.submodule as csub
+    ns.pcv_corr = pcorr
+    ns.cgi_sub = csub
     ns.corr = ccorr
     ns.update = cupdate
     ns.utils = cutils

@@ -100,6 +100,47 @@ def gen_corr(ref):
 
 
 @torch.no_grad()
+def gen_pcv(ref):
+    import warnings
+    print("PCVNet correlation block / CGI normalised volumes")
+    out = {}
+    for name, c in _cases.PCV_CASES.items():
+        f1, f2, coords, sigma = _cases.pcv_inputs(c)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # torch.range deprecation inside the reference
+            blk = ref.pcv_corr.CorrBlock1D(T(f1), T(f2), sample_num=c["S"], num_levels=c["L"], downsample=c["downsample"])
+            look = blk(T(coords), T(sigma)).numpy()
+        pyr = [flat(p.numpy()) for p in blk.corr_pyramid]
+        assert len(pyr) == c["L"]
+        for i, p in enumerate(pyr):
+            out["pcv/%s/pyr%d" % (name, i)] = p
+        out["pcv/%s/lookup" % name] = look
+        tp, factor = to.pcv_pyramid(T(f1), T(f2), c["L"], c["downsample"])
+        assert factor == blk.compress_factor
+        for i in range(c["L"]):
+            pin("torch.pcv_pyramid[%s][%d]" % (name, i), flat(tp[i].numpy()), pyr[i], 0.0)
+        pin("torch.pcv_lookup[%s]" % name, to.pcv_lookup(tp, T(coords), T(sigma), c["S"], factor).numpy(), look, 0.0)
+        cp = co.pcv_pyramid(pyr[0], c["L"], factor)
+        for i in range(c["L"]):
+            pin("c.pcv_pool[%s][%d] (from reference level 0)" % (name, i), cp[i], pyr[i], 0.0)
+        pin("c.pcv_lookup[%s] (on reference pyramid)" % name, co.pcv_lookup(pyr, coords, sigma, c["S"], factor), look, 0.0)
+    for name, c in _cases.NORMCORR_CASES.items():
+        a, b = _cases.volume_inputs(c)
+        v = ref.cgi_sub.build_gwc_volume_norm(T(a), T(b), c["D"], c["G"]).numpy()
+        out["normcorr/%s/gwc_norm" % name] = v
+        pin("torch.gwc_volume_norm[%s]" % name, to.gwc_volume_norm(T(a), T(b), c["D"], c["G"]).numpy(), v, 0.0)
+        pin("c.gwc_volume_norm[%s]" % name, co.gwc_volume_norm(a, b, c["D"], c["G"]), v, 1e-6)
+        if c["G"] == 1:
+            v1 = ref.cgi_sub.build_norm_correlation_volume(T(a), T(b), c["D"]).numpy()
+            v2 = ref.igev_sub.build_norm_correlation_volume(T(a), T(b), c["D"]).numpy()
+            assert np.array_equal(v1, v2)
+            out["normcorr/%s/norm_corr" % name] = v1
+            pin("torch.norm_correlation_volume[%s]" % name, to.norm_correlation_volume(T(a), T(b), c["D"]).numpy(), v1, 0.0)
+            pin("c.norm_correlation_volume[%s]" % name, co.gwc_volume_norm(a, b, c["D"], 1), v1, 1e-6)
+    save("pcv_cgi", **out)
+
+
+@torch.no_grad()
 def gen_geo(ref):
     print("IGEV geometry volume")
     out = {}
@@ -318,15 +359,22 @@ def main():
     co.build()
     ref = _refimport.load()
     only = set(sys.argv[1:])
-    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes),
+    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv),
             ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e)]
     for name, fn in gens:
         if not only or name in only:
             fn(ref)
-    if not only:
-        with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
-            json.dump(MANIFEST, f, indent=1, sort_keys=True)
-        print("wrote MANIFEST.json")
+    path = os.path.join(HERE, "MANIFEST.json")
+    if only and os.path.exists(path):                 # partial run: merge into the recorded pins
+        old = json.load(open(path))
+        old["pins"].update(MANIFEST["pins"])
+        for k, v in old.items():                      # keep everything the skipped generators recorded
+            if k != "pins" and k not in MANIFEST:
+                MANIFEST[k] = v
+        MANIFEST["pins"] = old["pins"]
+    with open(path, "w") as f:
+        json.dump(MANIFEST, f, indent=1, sort_keys=True)
+    print("wrote MANIFEST.json (%d pins)" % len(MANIFEST["pins"]))
 
 
 if __name__ == "__main__":

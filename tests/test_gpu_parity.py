@@ -497,3 +497,49 @@ def test_skew_lookup_fast_division_is_exact(W):
             x = base - r * 60 * (1 + rep)                       # smooth-ish, far left for large rep
         coords = torch.cat([x, torch.zeros_like(x)], 1).contiguous()
         assert torch.equal(blk(coords), _lookup(blk.corr_pyramid, coords, 4, W))
+
+
+
+@pytest.mark.parametrize("name", list(_cases.PCV_CASES))
+@torch.no_grad()
+def test_pcvnet_corr_block(name, golden, c_oracle):
+    """meta_arch/pcvnet/corr.py through dkt_pool_rows / dkt_pcv_lookup: pyramid levels > 0 and
+    the lookup are bit-exact on identical level-0 data; level 0 within contraction round-off."""
+    from dkt_stereo_amd.pcvnet_corr import CorrBlock1D
+    c = _cases.PCV_CASES[name]
+    f1, f2, coords, sigma = _cases.pcv_inputs(c)
+    g = golden("pcv_cgi")
+    blk = CorrBlock1D(G(f1), G(f2), sample_num=c["S"], num_levels=c["L"], downsample=c["downsample"])
+    assert len(blk.corr_pyramid) == c["L"] and blk.compress_factor == (4 if c["downsample"] == 2 else 2)
+    want0 = g["pcv/%s/pyr0" % name]
+    scale = max(float(np.abs(want0).max()), 1.0)
+    got = [p.view(p.shape[0], -1).cpu().numpy() for p in blk.corr_pyramid]
+    assert maxabs(got[0], want0) <= 4e-6 * scale
+    own = c_oracle.pcv_pyramid(got[0], c["L"], blk.compress_factor)          # pooling of OUR level 0
+    for i in range(1, c["L"]):
+        assert np.array_equal(got[i], own[i])
+        assert maxabs(got[i], g["pcv/%s/pyr%d" % (name, i)]) <= 4e-6 * scale
+    out = blk(G(coords), G(sigma)).cpu().numpy()
+    assert out.shape == g["pcv/%s/lookup" % name].shape
+    assert np.array_equal(out, c_oracle.pcv_lookup(got, coords, sigma, c["S"], blk.compress_factor))
+    assert maxabs(out, g["pcv/%s/lookup" % name]) <= 8e-6 * scale
+    # lookup alone on the reference's own pyramid: bit-exact
+    blk.corr_pyramid = [G(g["pcv/%s/pyr%d" % (name, i)]).view(-1, 1, 1, got[i].shape[1]) for i in range(c["L"])]
+    assert np.array_equal(blk(G(coords), G(sigma)).cpu().numpy(), g["pcv/%s/lookup" % name])
+
+
+@pytest.mark.parametrize("name", list(_cases.NORMCORR_CASES))
+@torch.no_grad()
+def test_cgi_norm_correlation_volumes(name, golden, c_oracle):
+    """meta_arch/cgi/submodule.py:143-180 through dkt_group_l2norm + dkt_gwc_volume."""
+    from dkt_stereo_amd.submodule import build_gwc_volume_norm, build_norm_correlation_volume
+    c = _cases.NORMCORR_CASES[name]
+    a, b = _cases.volume_inputs(c)
+    g = golden("pcv_cgi")
+    vol = build_gwc_volume_norm(G(a), G(b), c["D"], c["G"]).cpu().numpy()
+    assert maxabs(vol, g["normcorr/%s/gwc_norm" % name]) <= 1e-6
+    assert np.array_equal(vol, c_oracle.gwc_volume_norm(a, b, c["D"], c["G"]))    # same order -> bit exact
+    if c["G"] == 1:
+        v1 = build_norm_correlation_volume(G(a), G(b), c["D"]).cpu().numpy()
+        assert v1.shape == (c["B"], 1, c["D"], c["H"], c["W"])
+        assert maxabs(v1, g["normcorr/%s/norm_corr" % name]) <= 1e-6

@@ -103,6 +103,44 @@ def test_gwc_oracles(name, golden, c_oracle):
     assert maxabs(c_oracle.gwc_volume(a, b, c["D"], c["G"]), want) <= 2e-6
 
 
+@pytest.mark.parametrize("name", list(_cases.PCV_CASES))
+def test_pcv_oracles(name, golden, c_oracle):
+    """PCVNet correlation block (meta_arch/pcvnet/corr.py): pooling by the compress factor and
+    the sigma-spaced lookup -- both oracles reproduce the reference bit for bit."""
+    c = _cases.PCV_CASES[name]
+    f1, f2, coords, sigma = _cases.pcv_inputs(c)
+    g = golden("pcv_cgi")
+    pyr = [g["pcv/%s/pyr%d" % (name, i)] for i in range(c["L"])]
+    with torch.no_grad():
+        tp, factor = to.pcv_pyramid(T(f1), T(f2), c["L"], c["downsample"])
+        scale = max(float(np.abs(pyr[0]).max()), 1.0)
+        for i in range(c["L"]):
+            assert maxabs(flat(tp[i].numpy()), pyr[i]) <= 4e-6 * scale          # BLAS order of the host
+        ref_pyr = [T(p).view(p.shape[0], 1, 1, -1) for p in pyr]
+        assert maxabs(to.pcv_lookup(ref_pyr, T(coords), T(sigma), c["S"], factor).numpy(), g["pcv/%s/lookup" % name]) == 0.0
+    cp = c_oracle.pcv_pyramid(pyr[0], c["L"], factor)
+    for i in range(c["L"]):
+        assert np.array_equal(cp[i], pyr[i])
+    assert np.array_equal(c_oracle.pcv_lookup(pyr, coords, sigma, c["S"], factor), g["pcv/%s/lookup" % name])
+
+
+@pytest.mark.parametrize("name", list(_cases.NORMCORR_CASES))
+def test_norm_correlation_oracles(name, golden, c_oracle):
+    """CGI normalised volumes (meta_arch/cgi/submodule.py:143-180)."""
+    c = _cases.NORMCORR_CASES[name]
+    a, b = _cases.volume_inputs(c)
+    g = golden("pcv_cgi")
+    want = g["normcorr/%s/gwc_norm" % name]
+    with torch.no_grad():
+        assert maxabs(to.gwc_volume_norm(T(a), T(b), c["D"], c["G"]).numpy(), want) <= 1e-6
+    assert maxabs(c_oracle.gwc_volume_norm(a, b, c["D"], c["G"]), want) <= 1e-6
+    if c["G"] == 1:
+        w1 = g["normcorr/%s/norm_corr" % name]
+        with torch.no_grad():
+            assert maxabs(to.norm_correlation_volume(T(a), T(b), c["D"]).numpy(), w1) <= 1e-6
+        assert maxabs(c_oracle.gwc_volume_norm(a, b, c["D"], 1), w1) <= 1e-6
+
+
 @pytest.mark.parametrize("name", list(_cases.CONCAT_CASES))
 def test_concat_oracles(name, golden, c_oracle):
     c = _cases.CONCAT_CASES[name]
