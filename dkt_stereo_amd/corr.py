@@ -9,8 +9,11 @@ them unchanged:
     corr_fn = CorrBlock1D(fmap1, fmap2, radius=4, num_levels=4)
     corr = corr_fn(coords1)            # (B, L*(2r+1), H, W) float32 contiguous
 
-Inference only (the reference's training path needs autograd through
-grid_sample; that is a later row of SURVEY.md section 8f).
+``CorrBlock1D`` is differentiable w.r.t. the two feature maps: when they
+require grad the pyramid and every lookup are autograd nodes whose backward runs
+dkt_corr1d_lookup_bwd / dkt_corr1d_pool_bwd and two library GEMMs -- what autograd derives for
+the reference's grid_sample / avg_pool2d / einsum chain.  Coordinates must be detached, as the
+reference's callers do (raft_stereo.py:152).  The other classes are inference only.
 """
 import os
 
@@ -73,6 +76,63 @@ def _skew_pyramid(pyramid, B, H, W1, W2, out=None):
     return out
 
 
+class _BuildFn(torch.autograd.Function):
+    """(fmap1, fmap2) -> pyramid levels.  Backward: avg-pool chain + 1/sqrt(C) folded by
+    dkt_corr1d_pool_bwd, then grad_fmap1 = G x fmap2, grad_fmap2 = G^T x fmap1 (rocBLAS)."""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, num_levels, divisor):
+        pyr = _build_pyramid(fmap1, fmap2, num_levels, divisor)
+        ctx.save_for_backward(fmap1, fmap2)
+        ctx.meta = (num_levels, divisor)
+        return tuple(pyr)
+
+    @staticmethod
+    def backward(ctx, *glv):
+        f1, f2 = ctx.saved_tensors
+        L, divisor = ctx.meta
+        B, C, H, W1 = f1.shape
+        W2 = f2.shape[3]
+        N = B * H * W1
+        glv = [g.contiguous() if g is not None else torch.zeros((N, 1, 1, W2 >> i), device=f1.device)
+               for i, g in enumerate(glv)]
+        gvol = torch.empty((N, W2), device=f1.device, dtype=torch.float32)
+        rc = _ffi.lib().dkt_corr1d_pool_bwd(_ffi.ptr_array(glv), gvol.data_ptr(), B, H, W1, W2, L, float(divisor),
+                                            _ffi.device_of(gvol), _ffi.stream_of(gvol))
+        _ffi.check(rc, "dkt_corr1d_pool_bwd")
+        G = gvol.view(B, H, W1, W2)
+        gf1 = torch.einsum('bhwv,bchv->bchw', G, f2.float()) if ctx.needs_input_grad[0] else None
+        gf2 = torch.einsum('bhwv,bchw->bchv', G, f1.float()) if ctx.needs_input_grad[1] else None
+        return gf1, gf2, None, None
+
+
+class _LookupFn(torch.autograd.Function):
+    """(levels..., coords) -> lookup.  Backward scatters into zeroed level-shaped tensors."""
+
+    @staticmethod
+    def forward(ctx, coords, radius, w2, skew, *levels):
+        ctx.save_for_backward(coords)
+        ctx.meta = (radius, w2, [tuple(l.shape) for l in levels])
+        if skew is not None:
+            return _lookup(skew, coords, radius, w2, skewed=True)
+        return _lookup(list(levels), coords, radius, w2)
+
+    @staticmethod
+    def backward(ctx, gout):
+        coords, = ctx.saved_tensors
+        radius, w2, shapes = ctx.meta
+        B, _, H, W1 = coords.shape
+        if coords.stride(3) != 1 or coords.stride(2) != W1:
+            coords = coords.contiguous()
+        gout = gout.contiguous().float()
+        grads = [torch.zeros(s, device=gout.device, dtype=torch.float32) for s in shapes]
+        rc = _ffi.lib().dkt_corr1d_lookup_bwd(gout.data_ptr(), coords.data_ptr(), coords.stride(0),
+                                              _ffi.ptr_array(grads), B, H, W1, w2, len(grads), radius,
+                                              _ffi.device_of(gout), _ffi.stream_of(gout))
+        _ffi.check(rc, "dkt_corr1d_lookup_bwd")
+        return (None, None, None, None) + tuple(grads)
+
+
 class CorrBlock1D:
     """core/corr.py:110-156.  ``corr_pyramid`` holds the ``num_levels`` levels that
     ``__call__`` reads (the reference also stores one more pooled level that
@@ -96,13 +156,21 @@ class CorrBlock1D:
         lets a captured HIP graph of the lookup keep its pointers."""
         B, C, H, W1 = fmap1.shape
         # corr / sqrt(C) (core/corr.py:156); the kernel divides like the reference
-        self.corr_pyramid = _build_pyramid(fmap1.float(), fmap2.float(), self.num_levels,
-                                           float(torch.sqrt(torch.tensor(C).float())),
-                                           out=self.corr_pyramid)
+        divisor = float(torch.sqrt(torch.tensor(C).float()))
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            self.corr_pyramid = list(_BuildFn.apply(fmap1.float(), fmap2.float(), self.num_levels, divisor))
+        else:
+            self.corr_pyramid = _build_pyramid(fmap1.float(), fmap2.float(), self.num_levels, divisor,
+                                               out=self.corr_pyramid)
         if self.lookup_layout == "skew":
             self._skew = _skew_pyramid(self.corr_pyramid, B, H, W1, self._w2, out=self._skew)
 
     def __call__(self, coords):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.corr_pyramid):
+            if coords.requires_grad:
+                raise _ffi.DktError("CorrBlock1D: coordinate gradients are not implemented; detach the "
+                                    "coordinates as the reference's callers do (raft_stereo.py:152)")
+            return _LookupFn.apply(coords, self.radius, self._w2, self._skew, *self.corr_pyramid)
         if self._skew is not None:
             return _lookup(self._skew, coords, self.radius, self._w2, skewed=True)
         return _lookup(self.corr_pyramid, coords, self.radius, self._w2)
@@ -111,8 +179,11 @@ class CorrBlock1D:
     def corr(fmap1, fmap2):
         B, D, H, W1 = fmap1.shape
         W2 = fmap2.shape[3]
-        lvl0, = _build_pyramid(fmap1.float(), fmap2.float(), 1,
-                               float(torch.sqrt(torch.tensor(D).float())))
+        divisor = float(torch.sqrt(torch.tensor(D).float()))
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            lvl0, = _BuildFn.apply(fmap1.float(), fmap2.float(), 1, divisor)
+        else:
+            lvl0, = _build_pyramid(fmap1.float(), fmap2.float(), 1, divisor)
         return lvl0.view(B, H, W1, 1, W2)
 
 
@@ -147,6 +218,7 @@ class CorrBlock1D_Cosine(CorrBlock1D):
 
     @staticmethod
     def _normalise(fmap):
+        _ffi.require_no_grad(fmap)           # inference only: never detach silently
         fmap = fmap.float().contiguous()
         _ffi.require_gpu(fmap)
         B, C, H, W = fmap.shape

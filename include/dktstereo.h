@@ -107,6 +107,24 @@ int dkt_pool_w(const float *src, float *dst, long rows, int W, int device, void 
 int dkt_l2norm_channels(const float *src, float *dst, int B, int C, long HW,
                         int device, void *stream);
 
+/* ---- backward of lookup / pyramid (autograd of core/corr.py:119-146) -------- */
+
+/* Gradient of every pyramid level from the gradient of one lookup's output:
+ *   grad_pyr[i][n, x0] += g*(1-w),  grad_pyr[i][n, x0+1] += g*w   per tap (zero-padding taps drop out).
+ * grad_pyr: HOST array of L device pointers, shaped like the pyramid, ZEROED (or holding the
+ * sum of earlier lookups' gradients) by the caller.  coords are detached upstream
+ * (raft_stereo.py:152): no coordinate gradient. */
+int dkt_corr1d_lookup_bwd(const float *grad_out, const float *coords_x, long coords_bstride,
+                          float *const *grad_pyr, int B, int H, int W1, int W2, int L, int r,
+                          int device, void *stream);
+
+/* Folds the avg_pool2d backward chain and the 1/sqrt(C) of CorrBlock1D.corr into the gradient
+ * of the un-pooled all-pairs product: grad_vol (B*H*W1, W2) = T_0 / divisor with
+ * T_{L-1} = g_{L-1}, T_i[c] = g_i[c] + T_{i+1}[c/2]/2.  The two contractions that follow
+ * (grad_fmap1 = grad_vol x fmap2, grad_fmap2 = grad_vol^T x fmap1) are plain library GEMMs. */
+int dkt_corr1d_pool_bwd(const float *const *grad_pyr, float *grad_vol, int B, int H, int W1, int W2,
+                        int L, float divisor, int device, void *stream);
+
 /* ---- PCVNet correlation block / CGI normalised correlation -------- */
 
 /* F.avg_pool2d(x,[1,factor],stride=[1,factor]) on rows: src (rows,W) -> dst (rows,W/factor);

@@ -204,3 +204,30 @@ def group_l2norm(x, num_groups):
 def gwc_volume_norm(ref, tgt, maxdisp, num_groups):
     """cgi/submodule.py:143-164 (num_groups=1: build_norm_correlation_volume, :167-180)."""
     return gwc_volume(group_l2norm(ref, num_groups), group_l2norm(tgt, num_groups), maxdisp, num_groups)
+
+
+def corr1d_lookup_bwd(gout, coords, radius, widths, rows):
+    """Gradient of every pyramid level (zeros + scatter); widths: list of W2_i, rows = B*H*W1."""
+    gout, coords = _c(gout), _c(coords)
+    B, _, H, W1 = coords.shape
+    g = [np.zeros((rows, w), np.float32) for w in widths]
+    lib().orc_corr1d_lookup_bwd(_p(gout), _p(coords), _pp(g), B, H, W1, widths[0], len(widths), radius)
+    return g
+
+
+def corr1d_pool_bwd(gpyr, divisor):
+    gpyr = [_c(g) for g in gpyr]
+    g0 = np.empty_like(gpyr[0])
+    lib().orc_corr1d_pool_bwd(_pp(gpyr), _p(g0), ctypes.c_size_t(g0.shape[0]), g0.shape[1], len(gpyr), ctypes.c_float(divisor))
+    return g0
+
+
+def corr1d_build_bwd(g0_total, f1, f2):
+    """d/d fmap of sum_c f1*f2 given the (already /sqrt(C)) volume gradient: two contractions in fp64."""
+    f1, f2 = np.asarray(f1, np.float64), np.asarray(f2, np.float64)
+    B, C, H, W1 = f1.shape
+    W2 = f2.shape[3]
+    G = np.asarray(g0_total, np.float64).reshape(B, H, W1, W2)
+    gf1 = np.einsum('bhwv,bchv->bchw', G, f2)
+    gf2 = np.einsum('bhwv,bchw->bchv', G, f1)
+    return gf1.astype(np.float32), gf2.astype(np.float32)

@@ -486,4 +486,64 @@ void orc_group_l2norm(const float *x, float *y, int B, int C, int H, int W, int 
             }
 }
 
-int orc_version(void) { return 2; }
+
+/* ------------------------------------------------------------------------
+ * Backward of the RAFT lookup and pyramid (what autograd derives for
+ * core/corr.py:127-146 and :119-125).  coords are detached by the caller
+ * (raft_stereo.py:152), so only the gradient w.r.t. the volume exists.
+ *
+ * orc_corr1d_lookup_bwd: gpyr[i][n, x0] += g*e, gpyr[i][n, x0+1] += g*w for every tap
+ * (zero-padding taps contribute nothing), taps visited in k order like
+ * grid_sampler_2d_backward visits the sample points.  gpyr must be zeroed by the caller.
+ * ---------------------------------------------------------------------- */
+void orc_corr1d_lookup_bwd(const float *gout, const float *coords, float *const *gpyr,
+                           int B, int H, int W1, int W2, int L, int r)
+{
+    const int K = 2 * r + 1;
+    const size_t HW = (size_t)H * W1;
+    for (int b = 0; b < B; ++b)
+        for (size_t p = 0; p < HW; ++p) {
+            const size_t n = (size_t)b * HW + p;
+            const float cx = coords[(size_t)b * 2 * HW + p];
+            int wi = W2;
+            float div = 1.0f;
+            for (int i = 0; i < L; ++i) {
+                float *row = gpyr[i] + n * (size_t)wi;
+                const float wm1 = (float)(wi - 1);
+                const float xc = cx / div;
+                for (int k = 0; k < K; ++k) {
+                    const float x = (float)(k - r) + xc;
+                    const float xg = (2.0f * x) / wm1 - 1.0f;
+                    const float ix = (xg + 1.0f) * (wm1 / 2.0f);
+                    const float fl = floorf(ix);
+                    const float w = ix - fl, e = 1.0f - w;
+                    const float g = gout[((size_t)b * L * K + (size_t)i * K + k) * HW + p];
+                    if (fl >= 0.0f && fl <= wm1) row[(int)fl] += g * e;
+                    if (fl + 1.0f >= 0.0f && fl + 1.0f <= wm1) row[(int)fl + 1] += g * w;
+                }
+                wi /= 2;
+                div *= 2.0f;
+            }
+        }
+}
+
+/* Total gradient of the level-0 volume from the per-level gradients, i.e. the chain of
+ * avg_pool2d backward passes (each hands grad/2 to both inputs; the odd last column of a
+ * level receives nothing):  T_{L-1} = g_{L-1};  T_i[c] = g_i[c] + T_{i+1}[c/2] / 2;
+ * g0_total = T_0 / divisor   (divisor = sqrt(C): the backward of corr / sqrt(C)). */
+void orc_corr1d_pool_bwd(const float *const *gpyr, float *g0, size_t N, int W2, int L, float divisor)
+{
+    for (size_t n = 0; n < N; ++n)
+        for (int c = 0; c < W2; ++c) {
+            int deepest = 0;
+            for (int i = 1; i < L; ++i) {
+                if ((c >> i) < (W2 >> i)) deepest = i; else break;
+            }
+            float t = gpyr[deepest][n * (size_t)(W2 >> deepest) + (c >> deepest)];
+            for (int i = deepest - 1; i >= 0; --i)
+                t = gpyr[i][n * (size_t)(W2 >> i) + (c >> i)] + t / 2.0f;
+            g0[n * (size_t)W2 + c] = t / divisor;
+        }
+}
+
+int orc_version(void) { return 3; }

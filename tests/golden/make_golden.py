@@ -99,6 +99,41 @@ def gen_corr(ref):
     save("corr", **out)
 
 
+def gen_corr_bwd(ref):
+    """Autograd of the reference through lookup, pyramid and all-pairs correlation."""
+    print("corr lookup / build backward")
+    out = {}
+    for name, c in _cases.CORR_CASES.items():
+        f1, f2, coords = _cases.corr_inputs(c)
+        K = 2 * c["r"] + 1
+        R = _synth.normal((c["B"], c["L"] * K, c["H"], c["W"]), c["seed"], "gout")
+        a, b = T(f1).requires_grad_(True), T(f2).requires_grad_(True)
+        blk = ref.corr.CorrBlock1D(a, b, num_levels=c["L"], radius=c["r"])
+        look = blk(T(coords))
+        levels = blk.corr_pyramid[:c["L"]]
+        glv = torch.autograd.grad(look, levels, T(R), retain_graph=True, allow_unused=True)
+        gf1, gf2 = torch.autograd.grad(look, [a, b], T(R))
+        glv = [flat(g.numpy()) for g in glv]
+        for i, g in enumerate(glv):
+            out["%s/glevel%d" % (name, i)] = g
+        out["%s/gf1" % name] = gf1.numpy()
+        out["%s/gf2" % name] = gf2.numpy()
+        # --- pin the C restatement
+        widths = [c["W2"] >> i for i in range(c["L"])]
+        rows = c["B"] * c["H"] * c["W"]
+        cg = co.corr1d_lookup_bwd(R, coords, c["r"], widths, rows)
+        # autograd's gradient of level i is TOTAL (direct taps + what flows back through the
+        # pooled levels above it): compare with the pooled-back chain of the per-level scatters
+        for i in range(c["L"]):
+            pin("c.corr_lookup_bwd+pool_bwd[%s][%d]" % (name, i), co.corr1d_pool_bwd(cg[i:], 1.0), glv[i], 0.0)
+        g0 = co.corr1d_pool_bwd(cg, float(np.sqrt(np.float32(c["C"]))))
+        cf1, cf2 = co.corr1d_build_bwd(g0, f1, f2)
+        s1 = max(float(np.abs(gf1.numpy()).max()), 1.0)
+        pin("c.corr_build_bwd.f1[%s]" % name, cf1, gf1.numpy(), 4e-6 * s1)
+        pin("c.corr_build_bwd.f2[%s]" % name, cf2, gf2.numpy(), 4e-6 * max(float(np.abs(gf2.numpy()).max()), 1.0))
+    save("corr_bwd", **out)
+
+
 @torch.no_grad()
 def gen_pcv(ref):
     import warnings
@@ -359,7 +394,7 @@ def main():
     co.build()
     ref = _refimport.load()
     only = set(sys.argv[1:])
-    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv),
+    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd),
             ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e)]
     for name, fn in gens:
         if not only or name in only:

@@ -122,9 +122,12 @@ def test_lookup_strided_coords_and_errors():
         CorrBlock1D(G(f1), G(f2), num_levels=9, radius=4)
     with pytest.raises(_ffi.DktError):
         CorrBlock1D(G(f1), G(f2), num_levels=2, radius=9)(G(coords))
-    with torch.enable_grad():       # inference-only: autograd inputs are refused, not silently detached
+    with torch.enable_grad():       # the inference-only variants refuse autograd inputs, they never detach silently
+        from dkt_stereo_amd.corr import CorrBlock1D_Cosine
         with pytest.raises(_ffi.DktError):
-            CorrBlock1D(G(f1).requires_grad_(), G(f2), num_levels=2, radius=4)
+            CorrBlock1D_Cosine(G(f1).requires_grad_(), G(f2), num_levels=2, radius=4)
+        blk_g = CorrBlock1D(G(f1).requires_grad_(), G(f2), num_levels=2, radius=4)     # differentiable (8f-2)
+        assert blk_g.corr_pyramid[0].requires_grad
 
 
 # ---------------------------------------------------------------------------------
@@ -543,3 +546,56 @@ def test_cgi_norm_correlation_volumes(name, golden, c_oracle):
         v1 = build_norm_correlation_volume(G(a), G(b), c["D"]).cpu().numpy()
         assert v1.shape == (c["B"], 1, c["D"], c["H"], c["W"])
         assert maxabs(v1, g["normcorr/%s/norm_corr" % name]) <= 1e-6
+
+
+
+@pytest.mark.parametrize("name", list(_cases.CORR_CASES))
+def test_corr_backward(name, golden, c_oracle):
+    """Autograd through CorrBlock1D (dkt_corr1d_lookup_bwd / dkt_corr1d_pool_bwd + GEMMs) against
+    the reference's autograd (fixture) and the C oracle: the scatter is bit-exact on identical
+    inputs; feature gradients within contraction round-off."""
+    from dkt_stereo_amd.corr import CorrBlock1D
+    c = _cases.CORR_CASES[name]
+    f1, f2, coords = _cases.corr_inputs(c)
+    g = golden("corr_bwd")
+    K = 2 * c["r"] + 1
+    R = _synth.normal((c["B"], c["L"] * K, c["H"], c["W"]), c["seed"], "gout")
+    a, b = G(f1).requires_grad_(True), G(f2).requires_grad_(True)
+    blk = CorrBlock1D(a, b, num_levels=c["L"], radius=c["r"])
+    assert all(p.requires_grad for p in blk.corr_pyramid)
+    out = blk(G(coords))
+    with torch.no_grad():
+        ref_fwd = CorrBlock1D(G(f1), G(f2), num_levels=c["L"], radius=c["r"])(G(coords))
+    assert torch.equal(out.detach(), ref_fwd)                       # same forward kernels
+    glv = torch.autograd.grad(out, blk.corr_pyramid, G(R), retain_graph=True)
+    widths = [c["W2"] >> i for i in range(c["L"])]
+    cg = c_oracle.corr1d_lookup_bwd(R, coords, c["r"], widths, c["B"] * c["H"] * c["W"])
+    for i in range(c["L"]):
+        got = glv[i].view(glv[i].shape[0], -1).cpu().numpy()
+        assert np.array_equal(got, cg[i])                            # per-level scatter: bit exact
+    gf1, gf2 = torch.autograd.grad(out, [a, b], G(R))
+    for got, key in ((gf1, "gf1"), (gf2, "gf2")):
+        want = g["%s/%s" % (name, key)]
+        assert maxabs(got, want) <= 4e-6 * max(float(np.abs(want).max()), 1.0)
+    # coordinates must be detached, like the reference's callers do
+    with pytest.raises(Exception):
+        blk(G(coords).requires_grad_(True))
+
+
+def test_corr_backward_accumulates_over_lookups():
+    """Several lookups on one pyramid (the GRU loop): gradients of the feature maps add up."""
+    from dkt_stereo_amd.corr import CorrBlock1D
+    c = _cases.CORR_CASES["small"]
+    f1, f2, coords = _cases.corr_inputs(c)
+    a, b = G(f1).requires_grad_(True), G(f2).requires_grad_(True)
+    blk = CorrBlock1D(a, b, num_levels=c["L"], radius=c["r"])
+    c1, c2 = G(coords), G(coords) - 1.75
+    (blk(c1).sum() + 2.0 * blk(c2).sum()).backward()
+    both = a.grad.clone()
+    a.grad = None; b.grad = None
+    blk = CorrBlock1D(a, b, num_levels=c["L"], radius=c["r"])
+    blk(c1).sum().backward()
+    g1 = a.grad.clone(); a.grad = None
+    blk = CorrBlock1D(a, b, num_levels=c["L"], radius=c["r"])
+    (2.0 * blk(c2).sum()).backward()
+    assert float((both - (g1 + a.grad)).abs().max()) <= 2e-5 * float(both.abs().max())

@@ -103,6 +103,26 @@ def test_gwc_oracles(name, golden, c_oracle):
     assert maxabs(c_oracle.gwc_volume(a, b, c["D"], c["G"]), want) <= 2e-6
 
 
+@pytest.mark.parametrize("name", list(_cases.CORR_CASES))
+def test_corr_backward_oracle(name, golden, c_oracle):
+    """C restatement of the lookup / pyramid backward against the reference's autograd
+    (tests/golden/corr_bwd.npz): level gradients bit-exact, feature gradients within the
+    contraction's round-off."""
+    c = _cases.CORR_CASES[name]
+    f1, f2, coords = _cases.corr_inputs(c)
+    g = golden("corr_bwd")
+    K = 2 * c["r"] + 1
+    R = _synth.normal((c["B"], c["L"] * K, c["H"], c["W"]), c["seed"], "gout")
+    widths = [c["W2"] >> i for i in range(c["L"])]
+    cg = c_oracle.corr1d_lookup_bwd(R, coords, c["r"], widths, c["B"] * c["H"] * c["W"])
+    for i in range(c["L"]):
+        assert np.array_equal(c_oracle.corr1d_pool_bwd(cg[i:], 1.0), g["%s/glevel%d" % (name, i)])
+    g0 = c_oracle.corr1d_pool_bwd(cg, float(np.sqrt(np.float32(c["C"]))))
+    gf1, gf2 = c_oracle.corr1d_build_bwd(g0, f1, f2)
+    assert maxabs(gf1, g["%s/gf1" % name]) <= 4e-6 * max(float(np.abs(g["%s/gf1" % name]).max()), 1.0)
+    assert maxabs(gf2, g["%s/gf2" % name]) <= 4e-6 * max(float(np.abs(g["%s/gf2" % name]).max()), 1.0)
+
+
 @pytest.mark.parametrize("name", list(_cases.PCV_CASES))
 def test_pcv_oracles(name, golden, c_oracle):
     """PCVNet correlation block (meta_arch/pcvnet/corr.py): pooling by the compress factor and
