@@ -1,0 +1,98 @@
+// upsample.hip -- the up-sampling steps right after the GRU loop:
+//   dkt_convex_upsample   RAFTStereo.upsample_flow, meta_arch/raft_stereo/raft_stereo.py:70-82
+//                         (softmax over 9 + unfold + weighted sum + pixel shuffle in ONE pass;
+//                         torch runs it as softmax, mul-by-factor, im2col, mul, sum, permute copy)
+//   dkt_context_upsample  context_upsample, meta_arch/igev_stereo/submodule.py:242-254
+// HBM-bound: the mask / weight tensor (9*f*f resp. 9 planes at full resolution) is read once.
+#include "dkt_common.h"
+
+// thread = one full-resolution output pixel (Y, X), all D channels (the softmax is shared).
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float *__restrict__ flow,
+                                                              const float *__restrict__ mask,
+                                                              float *__restrict__ out,
+                                                              int D, int H, int W, int f, long total) {
+    const int Wf = W * f, Hf = H * f;
+    const long HW = (long)H * W;
+    for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int X = (int)(t % Wf);
+        const int Y = (int)((t / Wf) % Hf);
+        const int n = (int)(t / ((long)Wf * Hf));
+        const int w = X / f, j = X - w * f, h = Y / f, i = Y - h * f;
+        const float *mp = mask + ((long)n * 9 * f * f + (long)i * f + j) * HW + (long)h * W + w;
+        float m[9], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            m[k] = mp[(long)k * f * f * HW];
+            mx = fmaxf(mx, m[k]);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            m[k] = expf(__fsub_rn(m[k], mx));
+            sum = __fadd_rn(sum, m[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = __fdiv_rn(m[k], sum);
+        for (int d = 0; d < D; ++d) {
+            const float *fp = flow + ((long)n * D + d) * HW;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int hh = h + k / 3 - 1, ww = w + k % 3 - 1;
+                float v = 0.0f;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = __fmul_rn((float)f, fp[(long)hh * W + ww]);
+                acc = __fadd_rn(acc, __fmul_rn(m[k], v));
+            }
+            out[(((long)n * D + d) * Hf + Y) * Wf + X] = acc;
+        }
+    }
+}
+
+extern "C" int dkt_convex_upsample(const float *flow, const float *mask, float *out, int N, int D, int H, int W,
+                                   int factor, int device, void *stream) {
+    if (!flow || !mask || !out) return DKT_E_NULL;
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || factor < 1) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const long total = (long)N * H * factor * W * factor;
+    long blocks = (total + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       flow, mask, out, D, H, W, factor, total);
+    return dkt_launch_status();
+}
+
+__global__ __launch_bounds__(256) void context_upsample_kernel(const float *__restrict__ disp,
+                                                               const float *__restrict__ wts,
+                                                               float *__restrict__ out, int h, int w, long total) {
+    const int W4 = 4 * w, H4 = 4 * h;
+    const long plane = (long)H4 * W4;
+    for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int X = (int)(t % W4);
+        const int Y = (int)((t / W4) % H4);
+        const long b = t / plane;
+        const float *dp = disp + b * h * w;
+        const float *wp = wts + b * 9 * plane + (long)Y * W4 + X;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int hh = Y / 4 + k / 3 - 1, ww = X / 4 + k % 3 - 1;
+            float v = 0.0f;
+            if (hh >= 0 && hh < h && ww >= 0 && ww < w) v = dp[(long)hh * w + ww];
+            acc = __fadd_rn(acc, __fmul_rn(v, wp[(long)k * plane]));
+        }
+        out[t] = acc;
+    }
+}
+
+extern "C" int dkt_context_upsample(const float *disp_low, const float *up_weights, float *out, int B, int h, int w,
+                                    int device, void *stream) {
+    if (!disp_low || !up_weights || !out) return DKT_E_NULL;
+    if (B <= 0 || h <= 0 || w <= 0) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const long total = (long)B * 16 * h * w;
+    long blocks = (total + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(context_upsample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       disp_low, up_weights, out, h, w, total);
+    return dkt_launch_status();
+}

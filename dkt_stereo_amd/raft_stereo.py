@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _ffi
 from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
 from .extractor import BasicEncoder, MultiBasicEncoder
@@ -88,9 +89,18 @@ class RAFTStereo(nn.Module):
         return fmap1.float(), fmap2.float(), net_list, inp_list
 
     def upsample_flow(self, flow, mask):
-        """raft_stereo.py:70-82, convex combination over a 3x3 neighbourhood."""
+        """raft_stereo.py:70-82, convex combination over a 3x3 neighbourhood: one fused kernel
+        (dkt_convex_upsample) on the GPU inference path, the reference's op sequence otherwise."""
         N, D, H, W = flow.shape
         factor = 2 ** self.args.n_downsample
+        if flow.is_cuda and not (torch.is_grad_enabled() and (flow.requires_grad or mask.requires_grad)):
+            flow = flow.float().contiguous()
+            mask = mask.float().contiguous()
+            out = torch.empty((N, D, factor * H, factor * W), device=flow.device, dtype=torch.float32)
+            rc = _ffi.lib().dkt_convex_upsample(flow.data_ptr(), mask.data_ptr(), out.data_ptr(), N, D, H, W,
+                                                factor, _ffi.device_of(flow), _ffi.stream_of(flow))
+            _ffi.check(rc, "dkt_convex_upsample")
+            return out
         mask = torch.softmax(mask.view(N, 1, 9, factor, factor, H, W), dim=2)
         up = F.unfold(factor * flow, [3, 3], padding=1).view(N, D, 9, 1, 1, H, W)
         up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)

@@ -108,6 +108,22 @@ def build_norm_correlation_volume(refimg_fea, targetimg_fea, maxdisp):
     return build_gwc_volume_norm(refimg_fea, targetimg_fea, maxdisp, 1)
 
 
+def context_upsample(disp_low, up_weights):
+    """meta_arch/igev_stereo/submodule.py:242-254: (B,1,h,w), (B,9,4h,4w) -> (B,4h,4w)."""
+    _ffi.require_gpu(disp_low, up_weights)
+    _ffi.require_no_grad(disp_low, up_weights)
+    b, c, h, w = disp_low.shape
+    if c != 1 or tuple(up_weights.shape) != (b, 9, 4 * h, 4 * w):
+        raise ValueError("context_upsample: disp_low %s / up_weights %s" % (tuple(disp_low.shape), tuple(up_weights.shape)))
+    disp_low = disp_low.float().contiguous()
+    up_weights = up_weights.float().contiguous()
+    out = torch.empty((b, 4 * h, 4 * w), device=disp_low.device, dtype=torch.float32)
+    rc = _ffi.lib().dkt_context_upsample(disp_low.data_ptr(), up_weights.data_ptr(), out.data_ptr(), b, h, w,
+                                         _ffi.device_of(out), _ffi.stream_of(out))
+    _ffi.check(rc, "dkt_context_upsample")
+    return out
+
+
 def disparity_regression(x, maxdisp):
     """igev_stereo/submodule.py:220-224 (keepdim=True flavour)."""
     assert len(x.shape) == 4

@@ -107,6 +107,19 @@ int dkt_pool_w(const float *src, float *dst, long rows, int W, int device, void 
 int dkt_l2norm_channels(const float *src, float *dst, int B, int C, long HW,
                         int device, void *stream);
 
+/* ---- up-sampling after the loop ------------------------------------- */
+
+/* RAFTStereo.upsample_flow, meta_arch/raft_stereo/raft_stereo.py:70-82, in one pass:
+ * flow (N,D,H,W), mask (N,9*f*f,H,W) -> out (N,D,f*H,f*W);
+ * out[n,d,f*h+i,f*w+j] = sum_k softmax_k(mask[n,(k*f+i)*f+j,h,w]) * f*flow[n,d,h+ky-1,w+kx-1]. */
+int dkt_convex_upsample(const float *flow, const float *mask, float *out, int N, int D, int H, int W,
+                        int factor, int device, void *stream);
+
+/* context_upsample, meta_arch/igev_stereo/submodule.py:242-254: disp_low (B,1,h,w),
+ * up_weights (B,9,4h,4w) -> out (B,4h,4w). */
+int dkt_context_upsample(const float *disp_low, const float *up_weights, float *out, int B, int h, int w,
+                         int device, void *stream);
+
 /* ---- backward of lookup / pyramid (autograd of core/corr.py:119-146) -------- */
 
 /* Gradient of every pyramid level from the gradient of one lookup's output:

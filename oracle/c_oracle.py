@@ -231,3 +231,19 @@ def corr1d_build_bwd(g0_total, f1, f2):
     gf1 = np.einsum('bhwv,bchv->bchw', G, f2)
     gf2 = np.einsum('bhwv,bchw->bchv', G, f1)
     return gf1.astype(np.float32), gf2.astype(np.float32)
+
+
+def convex_upsample(flow, mask, factor):
+    flow, mask = _c(flow), _c(mask)
+    N, D, H, W = flow.shape
+    out = np.empty((N, D, factor * H, factor * W), np.float32)
+    lib().orc_convex_upsample(_p(flow), _p(mask), _p(out), N, D, H, W, factor)
+    return out
+
+
+def context_upsample(disp_low, up_weights):
+    disp_low, up_weights = _c(disp_low), _c(up_weights)
+    B, _, h, w = disp_low.shape
+    out = np.empty((B, 4 * h, 4 * w), np.float32)
+    lib().orc_context_upsample(_p(disp_low), _p(up_weights), _p(out), B, h, w)
+    return out

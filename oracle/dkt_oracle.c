@@ -546,4 +546,62 @@ void orc_corr1d_pool_bwd(const float *const *gpyr, float *g0, size_t N, int W2, 
         }
 }
 
-int orc_version(void) { return 3; }
+
+/* ------------------------------------------------------------------------
+ * Convex up-sampling, RAFTStereo.upsample_flow: meta_arch/raft_stereo/raft_stereo.py:70-82
+ *   mask (N, 9*f*f, H, W) viewed (N,1,9,f,f,H,W), softmax over the 9; flow (N,D,H,W)
+ *   out[n,d,f*h+i,f*w+j] = sum_k softmax_k(mask[n,(k*f+i)*f+j,h,w]) * f*flow[n,d,h+ky-1,w+kx-1]
+ * (k = 3*ky+kx, zero outside: F.unfold padding).  softmax = exp(x - max) / sum, sums in k order.
+ * ---------------------------------------------------------------------- */
+void orc_convex_upsample(const float *flow, const float *mask, float *out, int N, int D, int H, int W, int f)
+{
+    const size_t HW = (size_t)H * W;
+    for (int n = 0; n < N; ++n)
+        for (int h = 0; h < H; ++h)
+            for (int w = 0; w < W; ++w)
+                for (int i = 0; i < f; ++i)
+                    for (int j = 0; j < f; ++j) {
+                        float m[9], mx = -INFINITY, sum = 0.0f;
+                        for (int k = 0; k < 9; ++k) {
+                            m[k] = mask[((size_t)n * 9 * f * f + ((size_t)k * f + i) * f + j) * HW + (size_t)h * W + w];
+                            if (m[k] > mx) mx = m[k];
+                        }
+                        for (int k = 0; k < 9; ++k) {
+                            m[k] = expf(m[k] - mx);
+                            sum += m[k];
+                        }
+                        for (int d = 0; d < D; ++d) {
+                            float acc = 0.0f;
+                            for (int k = 0; k < 9; ++k) {
+                                const int hh = h + k / 3 - 1, ww = w + k % 3 - 1;
+                                float v = 0.0f;
+                                if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+                                    v = (float)f * flow[((size_t)n * D + d) * HW + (size_t)hh * W + ww];
+                                acc += (m[k] / sum) * v;
+                            }
+                            out[(((size_t)n * D + d) * H * f + (size_t)h * f + i) * (size_t)W * f + (size_t)w * f + j] = acc;
+                        }
+                    }
+}
+
+/* context_upsample: meta_arch/igev_stereo/submodule.py:242-254
+ *   disp_low (B,1,h,w), up_weights (B,9,4h,4w) -> (B,4h,4w):
+ *   out[b,Y,X] = sum_k unfold3x3(disp_low)[k, Y/4, X/4] * up_weights[b,k,Y,X]  (nearest up-sampling by 4) */
+void orc_context_upsample(const float *disp, const float *wts, float *out, int B, int h, int w)
+{
+    const int H4 = 4 * h, W4 = 4 * w;
+    for (int b = 0; b < B; ++b)
+        for (int Y = 0; Y < H4; ++Y)
+            for (int X = 0; X < W4; ++X) {
+                float acc = 0.0f;
+                for (int k = 0; k < 9; ++k) {
+                    const int hh = Y / 4 + k / 3 - 1, ww = X / 4 + k % 3 - 1;
+                    float v = 0.0f;
+                    if (hh >= 0 && hh < h && ww >= 0 && ww < w) v = disp[((size_t)b * h + hh) * w + ww];
+                    acc += v * wts[(((size_t)b * 9 + k) * H4 + Y) * W4 + X];
+                }
+                out[((size_t)b * H4 + Y) * W4 + X] = acc;
+            }
+}
+
+int orc_version(void) { return 4; }

@@ -484,3 +484,11 @@ def norm_correlation_volume(ref, tgt, maxdisp):
         else:
             vol[:, :, d, :, d:] = nc(ref[..., d:], tgt[..., :-d])
     return vol.contiguous()
+
+
+def context_upsample(disp_low, up_weights):
+    """meta_arch/igev_stereo/submodule.py:242-254."""
+    b, c, h, w = disp_low.shape
+    nb = F.unfold(disp_low.reshape(b, c, h, w), 3, 1, 1).reshape(b, -1, h, w)
+    nb = F.interpolate(nb, (h * 4, w * 4), mode='nearest').reshape(b, 9, h * 4, w * 4)
+    return (nb * up_weights).sum(1)

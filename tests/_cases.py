@@ -68,6 +68,32 @@ NORMCORR_CASES = {
 }
 
 
+# ---- up-sampling either side of the loop (raft_stereo.py:70-82, igev_stereo/submodule.py:242-254) ----
+UPSAMPLE_CASES = {
+    "f4":  dict(seed=101, N=2, D=2, H=5, W=7, nd=2),
+    "f2":  dict(seed=102, N=1, D=1, H=3, W=9, nd=1),
+    "f8":  dict(seed=103, N=1, D=2, H=2, W=3, nd=3),
+}
+CONTEXT_UP_CASES = {
+    "small": dict(seed=111, B=2, h=4, w=6),
+    "one":   dict(seed=112, B=1, h=1, w=5),
+}
+
+
+def upsample_inputs(c):
+    f = 2 ** c["nd"]
+    flow = _synth.normal((c["N"], c["D"], c["H"], c["W"]), c["seed"], "flow", scale=5.0)
+    mask = _synth.normal((c["N"], 9 * f * f, c["H"], c["W"]), c["seed"], "mask", scale=2.0)
+    return flow, mask, f
+
+
+def context_up_inputs(c):
+    disp = _synth.uniform((c["B"], 1, c["h"], c["w"]), 0.0, 48.0, c["seed"], "disp")
+    wts = _synth.normal((c["B"], 9, 4 * c["h"], 4 * c["w"]), c["seed"], "wts")
+    e = np.exp(wts - wts.max(axis=1, keepdims=True))
+    return disp, (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
 # ---- cost volumes ----------------------------------------------------------------
 GWC_CASES = {
     "igev":  dict(seed=31, B=2, C=96, H=3, W=24, D=8, G=8),      # cpg 12

@@ -99,6 +99,26 @@ def gen_corr(ref):
     save("corr", **out)
 
 
+@torch.no_grad()
+def gen_upsample(ref):
+    print("convex / context up-sampling")
+    out = {}
+    for name, c in _cases.UPSAMPLE_CASES.items():
+        flow, mask, f = _cases.upsample_inputs(c)
+        fake = SimpleNamespace(args=SimpleNamespace(n_downsample=c["nd"]))
+        want = ref.RAFTStereo.upsample_flow(fake, T(flow), T(mask)).numpy()
+        out["convex/%s" % name] = want
+        pin("torch.convex_upsample[%s]" % name, to.convex_upsample(T(flow), T(mask), f).numpy(), want, 0.0)
+        pin("c.convex_upsample[%s]" % name, co.convex_upsample(flow, mask, f), want, 2e-6 * float(np.abs(want).max()))
+    for name, c in _cases.CONTEXT_UP_CASES.items():
+        disp, wts = _cases.context_up_inputs(c)
+        want = ref.igev_sub.context_upsample(T(disp), T(wts)).numpy()
+        out["context/%s" % name] = want
+        pin("torch.context_upsample[%s]" % name, to.context_upsample(T(disp), T(wts)).numpy(), want, 0.0)
+        pin("c.context_upsample[%s]" % name, co.context_upsample(disp, wts), want, 2e-6 * float(np.abs(want).max()))
+    save("upsample", **out)
+
+
 def gen_corr_bwd(ref):
     """Autograd of the reference through lookup, pyramid and all-pairs correlation."""
     print("corr lookup / build backward")
@@ -394,7 +414,7 @@ def main():
     co.build()
     ref = _refimport.load()
     only = set(sys.argv[1:])
-    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd),
+    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd), ("upsample", gen_upsample),
             ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e)]
     for name, fn in gens:
         if not only or name in only:

@@ -599,3 +599,31 @@ def test_corr_backward_accumulates_over_lookups():
     blk = CorrBlock1D(a, b, num_levels=c["L"], radius=c["r"])
     (2.0 * blk(c2).sum()).backward()
     assert float((both - (g1 + a.grad)).abs().max()) <= 2e-5 * float(both.abs().max())
+
+
+
+@pytest.mark.parametrize("name", list(_cases.UPSAMPLE_CASES))
+@torch.no_grad()
+def test_convex_upsample(name, golden, c_oracle):
+    """dkt_convex_upsample vs RAFTStereo.upsample_flow (fixture) and the C oracle."""
+    from dkt_stereo_amd.raft_stereo import RAFTStereo, make_args
+    c = _cases.UPSAMPLE_CASES[name]
+    flow, mask, f = _cases.upsample_inputs(c)
+    fake = type("M", (), {"args": make_args(n_downsample=c["nd"])})()
+    got = RAFTStereo.upsample_flow(fake, G(flow), G(mask)).cpu().numpy()
+    want = golden("upsample")["convex/" + name]
+    assert got.shape == want.shape
+    assert maxabs(got, want) <= 4e-6 * float(np.abs(want).max())
+    assert maxabs(got, c_oracle.convex_upsample(flow, mask, f)) <= 4e-6 * float(np.abs(want).max())   # expf ulps
+
+
+@pytest.mark.parametrize("name", list(_cases.CONTEXT_UP_CASES))
+@torch.no_grad()
+def test_context_upsample(name, golden, c_oracle):
+    from dkt_stereo_amd.submodule import context_upsample
+    c = _cases.CONTEXT_UP_CASES[name]
+    disp, wts = _cases.context_up_inputs(c)
+    got = context_upsample(G(disp), G(wts)).cpu().numpy()
+    want = golden("upsample")["context/" + name]
+    assert got.shape == want.shape and maxabs(got, want) <= 2e-6 * float(np.abs(want).max())
+    assert np.array_equal(got, c_oracle.context_upsample(disp, wts))       # same order -> bit exact

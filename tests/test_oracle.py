@@ -123,6 +123,26 @@ def test_corr_backward_oracle(name, golden, c_oracle):
     assert maxabs(gf2, g["%s/gf2" % name]) <= 4e-6 * max(float(np.abs(g["%s/gf2" % name]).max()), 1.0)
 
 
+@pytest.mark.parametrize("name", list(_cases.UPSAMPLE_CASES))
+def test_convex_upsample_oracles(name, golden, c_oracle):
+    c = _cases.UPSAMPLE_CASES[name]
+    flow, mask, f = _cases.upsample_inputs(c)
+    want = golden("upsample")["convex/" + name]
+    with torch.no_grad():
+        assert maxabs(to.convex_upsample(T(flow), T(mask), f).numpy(), want) <= 2e-6 * float(np.abs(want).max())
+    assert maxabs(c_oracle.convex_upsample(flow, mask, f), want) <= 2e-6 * float(np.abs(want).max())
+
+
+@pytest.mark.parametrize("name", list(_cases.CONTEXT_UP_CASES))
+def test_context_upsample_oracles(name, golden, c_oracle):
+    c = _cases.CONTEXT_UP_CASES[name]
+    disp, wts = _cases.context_up_inputs(c)
+    want = golden("upsample")["context/" + name]
+    with torch.no_grad():
+        assert maxabs(to.context_upsample(T(disp), T(wts)).numpy(), want) <= 2e-6 * float(np.abs(want).max())
+    assert maxabs(c_oracle.context_upsample(disp, wts), want) <= 2e-6 * float(np.abs(want).max())
+
+
 @pytest.mark.parametrize("name", list(_cases.PCV_CASES))
 def test_pcv_oracles(name, golden, c_oracle):
     """PCVNet correlation block (meta_arch/pcvnet/corr.py): pooling by the compress factor and
