@@ -39,6 +39,21 @@ def setup():
             sys.modules[pkg] = m
 
 
+def load_frame_utils():
+    """core/utils/frame_utils.py with inert stand-ins for its cv2 / imageio imports (only the
+    pure numpy / PIL readers are exercised)."""
+    setup()
+    for name in ("cv2", "imageio"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "cv2":
+                m.setNumThreads = lambda n: None
+                m.ocl = types.SimpleNamespace(setUseOpenCL=lambda b: None)
+            sys.modules[name] = m
+    import core.utils.frame_utils as fu
+    return fu
+
+
 def load():
     """Returns a namespace with the reference's hot-path callables."""
     setup()

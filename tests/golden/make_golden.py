@@ -119,6 +119,45 @@ def gen_upsample(ref):
     save("upsample", **out)
 
 
+def gen_files(ref):
+    """Tiny dataset-format files + what the reference's readers return for them."""
+    from PIL import Image
+    print("on-disk formats (core/utils/frame_utils.py)")
+    fu = _refimport.load_frame_utils()
+    d = os.path.join(HERE, "files")
+    os.makedirs(os.path.join(d, "disparities"), exist_ok=True)
+    os.makedirs(os.path.join(d, "occlusions"), exist_ok=True)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    out = {}
+    disp = (rng.random((7, 11)) * 90).astype(np.float32)
+    fu.writePFM(os.path.join(d, "disp.pfm"), disp)                          # written by the reference
+    out["pfm"] = np.ascontiguousarray(fu.readPFM(os.path.join(d, "disp.pfm")))
+    rgb = (rng.random((5, 6, 3)) * 3).astype(np.float32)
+    with open(os.path.join(d, "color_be.pfm"), "wb") as f:                  # 3-channel, big endian
+        f.write(b"PF\n6 5\n1.0\n")
+        f.write(np.flipud(rgb).astype(">f4").tobytes())
+    out["pfm_color"] = np.ascontiguousarray(fu.readPFM(os.path.join(d, "color_be.pfm")))
+    out["read_gen_pfm_color"] = np.ascontiguousarray(fu.read_gen(os.path.join(d, "color_be.pfm")))
+    uv = rng.normal(size=(6, 9, 2)).astype(np.float32)
+    fu.writeFlow(os.path.join(d, "flow.flo"), uv)
+    out["flo"] = fu.readFlow(os.path.join(d, "flow.flo"))
+    k = (rng.random((8, 12)) * 60000).astype(np.uint16)
+    k[::3, ::4] = 0
+    Image.fromarray(k).save(os.path.join(d, "kitti_disp.png"))              # 16-bit grey, KITTI disp_occ_0 format
+    out["kitti_disp_expected"] = k.astype(np.float64) / 256.0               # cv2.imread(ANYDEPTH)/256.0, frame_utils.py:153
+    s = (rng.random((6, 7, 3)) * 255).astype(np.uint8)
+    Image.fromarray(s).save(os.path.join(d, "disparities", "frame.png"))
+    occ = ((rng.random((6, 7)) > 0.7) * 255).astype(np.uint8)
+    Image.fromarray(occ).save(os.path.join(d, "occlusions", "frame.png"))
+    sd, sv = fu.readDispSintelStereo(os.path.join(d, "disparities", "frame.png"))
+    out["sintel_disp"], out["sintel_valid"] = sd, sv
+    depth = (rng.random((4, 5)) * 50 + 0.5).astype(np.float32)
+    np.save(os.path.join(d, "depth.npy"), depth)
+    td, tv = fu.readDispTartanAir(os.path.join(d, "depth.npy"))
+    out["tartan_disp"], out["tartan_valid"] = td, tv
+    save("files", **out)
+
+
 def gen_corr_bwd(ref):
     """Autograd of the reference through lookup, pyramid and all-pairs correlation."""
     print("corr lookup / build backward")
@@ -414,7 +453,7 @@ def main():
     co.build()
     ref = _refimport.load()
     only = set(sys.argv[1:])
-    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd), ("upsample", gen_upsample),
+    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd), ("upsample", gen_upsample), ("files", gen_files),
             ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e)]
     for name, fn in gens:
         if not only or name in only:
