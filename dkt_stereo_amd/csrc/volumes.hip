@@ -50,6 +50,76 @@ __global__ __launch_bounds__(256) void gwc_volume_kernel(const float *__restrict
     }
 }
 
+// Groups wider than GWC_MAX_CPG channels (CGI's single-group normalised correlation: cpg = C):
+// same block mapping and the same sequential sum order, the reference values pass through
+// registers in chunks of 16 channels and the partial sums of a pixel stay in registers.
+// grid.y splits the disparities into chunks of GWC_BIG_DCHUNK planes (a single-group volume
+// has only B*H rows: one block per row would leave CUs idle).
+#define GWC_BIG_DCHUNK 16
+__global__ __launch_bounds__(256) void gwc_volume_big_kernel(const float *__restrict__ ref,
+                                                             const float *__restrict__ tgt,
+                                                             float *__restrict__ vol, int C, int H, int W,
+                                                             int D, int G, long vol_bstride) {
+    const int cpg = C / G;
+    const int h = blockIdx.x % H;
+    const int g = (blockIdx.x / H) % G;
+    const int b = blockIdx.x / (H * G);
+    const size_t HW = (size_t)H * W;
+    const size_t chan0 = ((size_t)b * C + (size_t)g * cpg) * HW + (size_t)h * W;
+    // one block per CU (the row set fills most of the LDS): the staging loads must overlap each
+    // other, so they are issued in batches of 8 independent loads (a plain loop waits per load)
+    const int n_el = cpg * W;
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 256 * k;
+            const int j = i / W, w = i - j * W;
+            v[k] = i < n_el ? tgt[chan0 + (size_t)j * HW + w] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + 256 * k < n_el) gwc_lds[i0 + 256 * k] = v[k];
+    }
+    __syncthreads();
+    const float fcpg = (float)cpg;
+    float *vrow = vol + (size_t)b * vol_bstride + (size_t)g * D * HW + (size_t)h * W;
+    const int d0 = blockIdx.y * GWC_BIG_DCHUNK;
+    for (int w = threadIdx.x; w < W; w += 256) {
+        float s[GWC_BIG_DCHUNK];
+#pragma unroll
+        for (int d = 0; d < GWC_BIG_DCHUNK; ++d) s[d] = 0.0f;
+        // Branch-free inner loops (a branch per product serialises the LDS latency: 420 us
+        // instead of ~60): disparities past D or left of the image border are computed on
+        // clamped indices and never stored; a partial last channel chunk takes the generic loop.
+        for (int j0 = 0; j0 < cpg; j0 += 16) {
+            const int nj = min(16, cpg - j0);
+            float r[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) r[j] = ref[chan0 + (size_t)(j0 + min(j, nj - 1)) * HW + w];
+            if (nj == 16) {
+#pragma unroll
+                for (int dd = 0; dd < GWC_BIG_DCHUNK; ++dd) {
+                    const float *lp = gwc_lds + j0 * W + max(w - (d0 + dd), 0);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) s[dd] = __fadd_rn(s[dd], __fmul_rn(r[j], lp[j * W]));
+                }
+            } else {
+#pragma unroll
+                for (int dd = 0; dd < GWC_BIG_DCHUNK; ++dd) {
+                    const float *lp = gwc_lds + j0 * W + max(w - (d0 + dd), 0);
+                    for (int j = 0; j < nj; ++j) s[dd] = __fadd_rn(s[dd], __fmul_rn(r[j], lp[j * W]));
+                }
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < GWC_BIG_DCHUNK; ++dd) {
+            const int d = d0 + dd;
+            if (d < D) vrow[(size_t)d * HW + w] = w >= d ? __fdiv_rn(s[dd], fcpg) : 0.0f;
+        }
+    }
+}
+
 extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
                               int B, int C, int H, int W, int D, int G, long vol_bstride,
                               int device, void *stream) {
@@ -57,7 +127,7 @@ extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0 || G <= 0) return DKT_E_SHAPE;
     if (C % G != 0) return DKT_E_GROUPS;
     const int cpg = C / G;
-    if (cpg > GWC_MAX_CPG) return DKT_E_UNSUPPORTED;
+    const bool big = cpg > GWC_MAX_CPG;
     if (vol_bstride < (long)G * D * H * W) return DKT_E_SHAPE;
     size_t lds = (size_t)cpg * W * sizeof(float);
     if (lds > 160 * 1024) return DKT_E_UNSUPPORTED;
@@ -65,12 +135,17 @@ extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
     if (blocks > 0x7FFFFFFFull) return DKT_E_SHAPE;
     DKT_ENTER(device);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)gwc_volume_kernel,
+        hipError_t e = hipFuncSetAttribute(big ? (const void *)gwc_volume_big_kernel : (const void *)gwc_volume_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(gwc_volume_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
-                       ref, tgt, vol, C, H, W, D, G, vol_bstride);
+    if (big)
+        hipLaunchKernelGGL(gwc_volume_big_kernel,
+                           dim3((unsigned)blocks, (unsigned)((D + GWC_BIG_DCHUNK - 1) / GWC_BIG_DCHUNK)), dim3(256), lds, (hipStream_t)stream,
+                           ref, tgt, vol, C, H, W, D, G, vol_bstride);
+    else
+        hipLaunchKernelGGL(gwc_volume_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
+                           ref, tgt, vol, C, H, W, D, G, vol_bstride);
     return dkt_launch_status();
 }
 

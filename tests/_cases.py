@@ -65,6 +65,7 @@ NORMCORR_CASES = {
     "cgi":  dict(seed=91, B=2, C=12, H=3, W=24, D=8, G=1),
     "g4":   dict(seed=92, B=1, C=32, H=2, W=30, D=12, G=4),
     "dgtw": dict(seed=93, B=1, C=6, H=2, W=5, D=7, G=2),
+    "wide": dict(seed=94, B=1, C=48, H=2, W=40, D=12, G=1),      # one group wider than 16 channels (CGI: cpg = C)
 }
 
 
@@ -100,6 +101,7 @@ GWC_CASES = {
     "gwc":   dict(seed=32, B=1, C=320, H=2, W=30, D=12, G=40),   # cpg 8
     "dgtw":  dict(seed=33, B=1, C=8, H=2, W=6, D=9, G=2),        # D > W: empty slices
     "g1":    dict(seed=34, B=1, C=5, H=2, W=17, D=4, G=1),
+    "cpg40": dict(seed=35, B=1, C=80, H=2, W=21, D=6, G=2),      # groups wider than 16 channels
 }
 CONCAT_CASES = {
     "gc":   dict(seed=41, B=2, C=12, H=3, W=24, D=8),

@@ -108,5 +108,5 @@ def test_abi_argument_errors_before_launch():
     assert lib.dkt_corr1d_build(p, p, pp, 1, 1, 1, 4, 4, 4, 1.0, -1, null) == -3      # 4 >> 3 == 0
     assert lib.dkt_corr1d_lookup(pp, p, 8, p, 1, 1, 4, 4, 1, 9, -1, null) == -4       # radius > 8
     assert lib.dkt_gwc_volume(p, p, p, 1, 6, 1, 4, 2, 4, 64, -1, null) == -5          # 6 % 4
-    assert lib.dkt_gwc_volume(p, p, p, 1, 64, 1, 4, 2, 2, 64, -1, null) == -7         # cpg 32 > 16
+    assert lib.dkt_gwc_volume(p, p, p, 1, 8192, 1, 16, 2, 1, 32, -1, null) == -7     # one group's target row > 160 KB of LDS
     assert lib.dkt_concat_volume(p, p, p, 1, 2, 1, 4, 2, 1, 3, -1, null) == -2        # bstride too small

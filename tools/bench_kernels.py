@@ -270,10 +270,60 @@ def bench_volumes():
     report("geo_lookup IGEV cfg3", timeit(lambda: fn(disp, coords), n=50), bytes_=184 * 312 * 1376)
 
 
+def bench_next():
+    """SURVEY 8f rows at cfg2 / cfg3 sizes: PCVNet lookup, CGI normalised volume, lookup / pyramid
+    backward, fused convex up-sampling (vs the torch op sequence)."""
+    import torch.nn.functional as F
+    from dkt_stereo_amd.corr import CorrBlock1D
+    from dkt_stereo_amd.pcvnet_corr import CorrBlock1D as PcvBlock
+    from dkt_stereo_amd.raft_stereo import RAFTStereo, make_args
+    from dkt_stereo_amd.submodule import build_norm_correlation_volume
+    H, W = 184, 312
+    g = torch.Generator(device=DEV).manual_seed(0)
+    with torch.no_grad():
+        f1, f2 = (torch.randn(1, 256, H, W, device=DEV, generator=g) for _ in range(2))
+        Gn, S, L = 2, 9, 3
+        blk = PcvBlock(f1, f2, sample_num=S, num_levels=L, downsample=2)
+        base = torch.arange(W, device=DEV).float().view(1, 1, 1, W).expand(1, Gn, H, W)
+        coords = (base - 40 * torch.rand(1, Gn, H, W, device=DEV, generator=g)).contiguous()
+        sigma = (0.5 + 2 * torch.rand(1, Gn, H, W, device=DEV, generator=g)).contiguous()
+        alg = H * W * (L * Gn * S * (8 + 4) + Gn * 8)       # 2 floats read + 1 written per tap, coords + sigma
+        report("pcv_lookup G=2 S=9 L=3 (factor 4)", timeit(lambda: blk(coords, sigma), n=100), bytes_=alg)
+        a, b = (torch.randn(1, 96, H, W, device=DEV, generator=g) for _ in range(2))
+        alg = 2 * 2 * 96 * H * W * 4 + 2 * 96 * H * W * 4 + 48 * H * W * 4   # normalise (r+w) both maps, read them, write volume
+        report("norm_correlation_volume 96ch D=48", timeit(lambda: build_norm_correlation_volume(a, b, 48), n=50), bytes_=alg)
+        flow = torch.randn(1, 2, H, W, device=DEV, generator=g)
+        mask = torch.randn(1, 144, H, W, device=DEV, generator=g)
+        fake = type("M", (), {"args": make_args(n_downsample=2)})()
+        alg = (144 + 2) * H * W * 4 + 2 * 16 * H * W * 4
+        report("convex_upsample fused (dkt)", timeit(lambda: RAFTStereo.upsample_flow(fake, flow, mask), n=100), bytes_=alg)
+
+        def torch_up():
+            m = torch.softmax(mask.view(1, 1, 9, 4, 4, H, W), dim=2)
+            up = F.unfold(4 * flow, [3, 3], padding=1).view(1, 2, 9, 1, 1, H, W)
+            return torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(1, 2, 4 * H, 4 * W)
+        report("convex_upsample torch op sequence", timeit(torch_up, n=50), bytes_=alg)
+    # backward: 1 lookup's gradient -> level grads (zero-fill + scatter), then pooled chain + 2 GEMMs
+    a1 = f1.clone().requires_grad_(True)
+    b1 = f2.clone().requires_grad_(True)
+    cb = CorrBlock1D(a1, b1, num_levels=4, radius=4)
+    xy = torch.zeros(1, 2, H, W, device=DEV)
+    xy[:, 0] = torch.arange(W, device=DEV).float().view(1, 1, W) - 30 * torch.rand(1, H, W, device=DEV, generator=g)
+    out = cb(xy)
+    go = torch.randn_like(out)
+    pyr_bytes = 4 * H * W * (312 + 156 + 78 + 39)
+    report("lookup backward (zero-fill + scatter, 4 levels)",
+           timeit(lambda: torch.autograd.grad(out, cb.corr_pyramid, go, retain_graph=True), n=30),
+           bytes_=pyr_bytes + out.numel() * 4)
+    report("lookup + pyramid + corr backward -> grad fmaps",
+           timeit(lambda: torch.autograd.grad(out, [a1, b1], go, retain_graph=True), n=20),
+           flops=2 * 2.0 * H * W * W * 256)
+
+
 def main():
     which = sys.argv[1:] or ["lookup", "build", "gates", "conv", "e2e", "autocast", "volumes"]
     fns = dict(lookup=bench_lookup, build=bench_build, gates=bench_gates, conv=bench_conv, e2e=bench_e2e,
-               autocast=bench_autocast, volumes=bench_volumes, ablate=bench_ablate)
+               autocast=bench_autocast, volumes=bench_volumes, ablate=bench_ablate, next=bench_next)
     for w in which:
         print("== %s ==" % w, flush=True)
         try:
