@@ -249,6 +249,15 @@ def main():
     conv_avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
     conv_alg_flops = 2.0 * n_pix * 384 * 9 * 256
     conv_tflops_exec = passes * conv_alg_flops / (conv_avg_ms * 1e-3) / 1e12 if conv_avg_ms > 0 else 0.0
+    # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    # rocprofv3 runs of the same kernels on the same shapes); None when the file is absent
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            traffic = json.load(f)
+    except (OSError, ValueError):
+        pass
+    default_shape = (args.height, args.width, B) == (736, 1248, 1)
     out = {
         "metric": "stereo pairs/sec at 736x1248 D=192, 32 iters (RAFT-Stereo test_mode forward)",
         "value": world * B * args.steps / elapsed,
@@ -275,7 +284,9 @@ def main():
         # against the dense fp16 MFMA peak.
         "roofline": {"kernel": "conv2d_f16s_kernel (dkt_conv2d_f16s_gate_zr), gru08 z|r 384->256 3x3 + gate epilogue @%dx%d" % (h4, w4),
                      "bound": "mfma", "achieved": conv_tflops_exec, "peak": FP16_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": conv_tflops_exec / FP16_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": conv_tflops_exec / FP16_MFMA_PEAK_TFLOPS,
+                     "traffic": traffic.get("conv_zr_gate_bytes") if default_shape else None,
+                     "traffic_source": traffic.get("source") if default_shape else None,
                      "algorithmic_flops_per_launch_fp32_equiv": conv_alg_flops, "mfma_passes": passes,
                      "fp32_equivalent_tflops": conv_tflops_exec / passes,
                      "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
@@ -284,7 +295,8 @@ def main():
         # the kernel BASELINE.json's north_star sets the HBM target for
         "roofline_lookup": {"kernel": "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": traffic.get("lookup_b1_bytes") if default_shape else None,
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
                             "launches_timed": len(look_ms)},
     }

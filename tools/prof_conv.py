@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one hot-path kernel in isolation a few times (for rocprofv3 --pmc / --kernel-trace).
-usage: prof_conv.py [zr|q|enc|lookup|build] [reps]"""
+usage: prof_conv.py [zr|zr_gate|q|enc|lookup|build] [reps]"""
 import os
 import sys
 
@@ -23,6 +23,13 @@ with torch.no_grad():
         xs = [torch.randn(1, 128, 184, 312, device=dev) for _ in range(3)]
         for _ in range(reps):
             conv.conv2d(xs, layer)
+    elif which == "zr_gate":      # the dominant kernel of bench.py: gru08 z|r convolution with the gate epilogue
+        conv.set_backend("f16x3")
+        layer = torch.nn.Conv2d(384, 256, 3, padding=1).to(dev)
+        xs = [torch.tanh(torch.randn(1, 128, 184, 312, device=dev))] + [torch.randn(1, 128, 184, 312, device=dev) for _ in range(2)]
+        cz, cr = (torch.randn(1, 128, 184, 312, device=dev) for _ in range(2))
+        for _ in range(reps):
+            conv.conv2d_gate_zr(xs, layer, cz, cr, xs[0])
     elif which == "enc":          # narrow encoder layer: 64->64 3x3 at 368x624
         conv.set_backend("f16x3")
         layer = torch.nn.Conv2d(64, 64, 3, padding=1).to(dev)
