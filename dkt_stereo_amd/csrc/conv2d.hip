@@ -27,8 +27,8 @@
 //       block (a block spans up to 256 output channels, so a patch is staged once);
 //   D accumulators keep pixels along lanes (C/D map col = l&31), so output
 //       stores are 128-byte NCHW rows.
-// Block = 4 waves inside a 256-VGPR budget (two blocks per CU).  Wave tile = 64 output
-// channels x NF rows x 32 columns; WM x WN waves along (channels, rows).  Blocks are
+// Block = 4 waves inside a 256-VGPR budget (two blocks per CU).  Wave tile = 32*MF output
+// channels (MF = 2; 1 for the 1-2 channel heads) x NF rows x 32 columns; WM x WN waves along (channels, rows).  Blocks are
 // persistent (a stream of tiles per block); LDS is double buffered: the fp32 loads of
 // chunk c+1 -- of this tile or the block's next one -- are in flight under the MFMAs of
 // chunk c; one barrier per chunk.
@@ -114,7 +114,7 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2>
 __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int HALO = KS / 2;
     constexpr int TR = NF * WN;              // output rows per block
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
         const int xy = t % a.tiles_xy, r = t / a.tiles_xy;
         tw0 = (xy % a.tiles_w) * 32;
         th0 = (xy / a.tiles_w) * TR;
-        tco = (r % a.n_co) * (64 * WM);
+        tco = (r % a.n_co) * (32 * MF * WM);
         tb = r / a.n_co;
     };
     int h0, w0, co_blk, b;            // tile being computed
@@ -230,10 +230,10 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
         }
     };
 
-    f32x16 acc[2][NF];
+    f32x16 acc[MF][NF];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MF; ++m)
 #pragma unroll
             for (int n = 0; n < NF; ++n)
 #pragma unroll
@@ -245,20 +245,20 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
     // weight fragment base (halves): ((tap*nch16 + ch16)*CoutPad + co)*16 + kg*8; waves past
     // the (64-padded) channel count idle on clamped weights
     auto wlane_of = [&](int tco) {
-        const int cw = tco + wm * 64;
+        const int cw = tco + wm * 32 * MF;
         return ((long)((cw < a.CoutPad ? cw : 0) + li)) * 16 + kg * 8;
     };
     long wl_cur = wlane_of(co_blk), wl_nxt = wl_cur;   // weight bases of the computed / the following tile
     const long wstep = (long)a.CoutPad * 16;           // one 16-channel slab
     const int nchunks = a.nch16 / 2;
 
-    f16x8 Ahi[AR][2], Alo[AR][2];
+    f16x8 Ahi[AR][MF], Alo[AR][MF];
     f16x8 Bhi[2][NF], Blo[2][NF];
     auto loadA = [&](int slot, long wlane, int chunk, int step) {
         const int tap = step >> 1, kh = step & 1;
         const long wbase = ((long)tap * a.nch16 + (chunk * 2 + kh)) * wstep + wlane;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MF; ++m) {
             Ahi[slot][m] = *(const f16x8 *)(a.whi + wbase + m * 32 * 16);
             if (PASSES >= 2) Alo[slot][m] = *(const f16x8 *)(a.wlo + wbase + m * 32 * 16);
         }
@@ -281,20 +281,20 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MF; ++m)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[as][m], Bhi[bs][n], acc[m][n], 0, 0, 0);
         if (PASSES >= 2) {
 #pragma unroll
             for (int n = 0; n < NF; ++n)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MF; ++m)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[as][m], Bhi[bs][n], acc[m][n], 0, 0, 0);
         }
         if (PASSES == 3) {
 #pragma unroll
             for (int n = 0; n < NF; ++n)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MF; ++m)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[as][m], Blo[bs][n], acc[m][n], 0, 0, 0);
         }
     };
@@ -310,20 +310,20 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
     // a wave-uniform branch here would split the scheduling region.
     auto epilogue = [&]() {
         // ---- epilogue: un-scale, bias, optional ReLU, NCHW stores (128-byte rows) ----
-        const int co_w = co_blk + wm * 64;                 // this wave's first output channel
+        const int co_w = co_blk + wm * 32 * MF;            // this wave's first output channel
         if (co_w >= a.CoutPad) return;                     // idle wave
         // this lane's 32 output channels: co = co_lane + m*32 + (r&3) + 8*(r>>2); their biases
         // are fetched as one batch of independent loads (clamped index, no per-element branch)
         const int co_lane = co_w + 4 * kg;
-        float bv[2][16];
+        float bv[MF][16];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MF; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_lane + m * 32 + (r & 3) + 8 * (r >> 2);
                 bv[m][r] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f;
             }
-        const bool all_co = co_w + 64 <= a.Cout;            // wave-uniform: no channel guard needed
+        const bool all_co = co_w + 32 * MF <= a.Cout;            // wave-uniform: no channel guard needed
         const int iHW = (int)HW;
         if (a.epi == 0) {
             float *ob = a.out + (long)b * a.out_bs + (long)co_lane * HW;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
                 if (oh >= a.H || ow >= a.W) continue;
                 float *op = ob + (long)oh * a.W + ow;
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MF; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
             if (oh >= a.H || ow >= a.W) continue;
             const long px = (long)oh * a.W + ow;
 #pragma unroll
-            for (int mh = 0; mh < 4; ++mh) {
+            for (int mh = 0; mh < 2 * MF; ++mh) {
                 // the gate operands of 8 channels are fetched as one batch BEFORE any store (hout
                 // may alias h, so the compiler cannot hoist the loads over stores itself); batches
                 // of 8 rather than 16 keep the kernel inside the 256-VGPR budget of two blocks/CU
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
 
     constexpr int HALF = NSTEP / 2;
     constexpr int PER = (NSL + HALF - 1) / HALF;
-    constexpr int NMMA = 2 * NF * PASSES;
+    constexpr int NMMA = MF * NF * PASSES;
     stage_tile(h0, w0);
     stage_select(b, 0);
     stage_load(0, NSL);
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
                 if (!(ABL & 8)) mma(s % AR, s & 1);
                 else {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(Ahi[s % AR][m]), "v"(Alo[s % AR][m]));
+                    for (int m = 0; m < MF; ++m) asm volatile("" ::"v"(Ahi[s % AR][m]), "v"(Alo[s % AR][m]));
 #pragma unroll
                     for (int n = 0; n < NF; ++n) asm volatile("" ::"v"(Bhi[s & 1][n]), "v"(Blo[s & 1][n]));
                 }
@@ -553,13 +553,13 @@ static int conv_slots(const void *kern, size_t lds, int dev) {
     return per_cu * cus;
 }
 
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2>
 static int launch_conv(ConvArgs a, int B, hipStream_t st) {
     constexpr int HALO = KS / 2;
     constexpr int NPP = (NF * WN + 2 * HALO) * (32 + 2 * HALO);
     constexpr int STAGE = NPP * 20 * (PASSES == 3 ? 2 : 1);
     const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);   // + dummy words for surplus staging lanes
-    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL>;
+    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF>;
     // once per device and instantiation (and never inside a stream capture after warm-up)
     static int slots[64] = {0};                        // benign race: worst case computed twice
     int dev = 0;
@@ -573,7 +573,7 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
     }
     const int tiles_h = (a.H + NF * WN - 1) / (NF * WN);
     a.tiles_xy = a.tiles_w * tiles_h;
-    a.n_co = (a.Cout + 64 * WM - 1) / (64 * WM);
+    a.n_co = (a.Cout + 32 * MF * WM - 1) / (32 * MF * WM);
     const long total = (long)a.tiles_xy * a.n_co * B;
     if (total > 0x7fffffffL) return DKT_E_SHAPE;
     a.total_tiles = (int)total;
@@ -591,7 +591,7 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
 template <int KS, int PASSES>
 static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     const long tiles4 = (long)a.tiles_w * ((a.H + 3) / 4) * B;    // blocks if a block covers 4 rows
-    static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5|6|7 forces a tile shape
+    static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5|6|7|8 forces a tile shape
         const char *e = getenv("DKT_CONV_CFG");
         return e ? atoi(e) : 0;
     }();
@@ -601,6 +601,7 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     case 5: return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);
     case 6: return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);
     case 7: return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);
+    case 8: return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st);
     default: break;
     }
     // 4-row blocks keep the LDS stage at 65 KB, i.e. two blocks per CU; the 8-row forms
@@ -609,6 +610,8 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     // take half-height tiles so that twice as many CUs work.
     (void)tiles4;
     const long few = CONV_FEW_TILES;
+    // the flow / disparity heads (2 and 1 output channels): a 32-channel wave tile halves the padded MFMA work
+    if (a.Cout <= 32) return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st);  // 32 co x 4 rows
     if (a.Cout <= 64) return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);            // 64 co x 4 rows
     if (a.Cout <= 128) {
         if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);        // 128 co x 2 rows
