@@ -46,6 +46,8 @@ SIGNATURES = {
     "dkt_conv2d_pack_weights": [_vp, _ip, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_f16s": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_conv2d_f16s_strided": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
+                                _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_f16s_gate_zr": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
                                 _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_f16s_gate_out": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l,

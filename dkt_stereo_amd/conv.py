@@ -14,8 +14,8 @@ Backends (``set_backend``; default "f16x3"):
   "miopen"   vendor fp32 convolution via torch (concatenates list inputs).
   "f16x2"    passes=2: activations rounded to fp16, weights split.
   "f16"      passes=1: plain fp16 operands, fp32 accumulate.
-Kernel sizes other than 1x1 / 3x3 (the 7x7 flow stem with 1-2 input channels)
-and strided convolutions always use the vendor path.
+1x1 / 3x3 layers with padding K/2 and stride 1 or 2 run on the kernel; the 7x7 stems on
+dkt_conv2d_direct; anything else on the vendor path.
 """
 import ctypes
 import math
@@ -43,7 +43,7 @@ def get_backend():
 def _vendor(x, layer, relu):
     if isinstance(x, (list, tuple)):
         x = x[0] if len(x) == 1 else torch.cat(list(x), dim=1)
-    y = F.conv2d(x, layer.weight, layer.bias, stride=1, padding=layer.padding)
+    y = F.conv2d(x, layer.weight, layer.bias, stride=_stride_of(layer), padding=layer.padding)
     return torch.relu_(y) if relu else y
 
 
@@ -103,12 +103,20 @@ def _dense(t):
     return t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == hw
 
 
+def _stride_of(layer):
+    st = getattr(layer, "stride", 1)
+    st = (st, st) if isinstance(st, int) else tuple(st)
+    return st
+
+
 def hip_eligible(layer):
-    """True when `layer` runs on dkt_conv2d_f16s under the current backend."""
+    """True when `layer` runs on dkt_conv2d_f16s[_strided] under the current backend:
+    1x1 / 3x3, padding K/2, stride 1 or 2."""
     kh, kw = layer.weight.shape[2:]
     pad = layer.padding
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
-    return _BACKEND in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2)
+    return (_BACKEND in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2)
+            and _stride_of(layer) in ((1, 1), (2, 2)))
 
 
 def direct_eligible(layer):
@@ -120,7 +128,7 @@ def direct_eligible(layer):
     cout, cin, kh, kw = layer.weight.shape
     pad = layer.padding
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
-    if kh != kw or pad != (kh // 2, kw // 2):
+    if kh != kw or pad != (kh // 2, kw // 2) or _stride_of(layer) != (1, 1):
         return False
     return kh == 7 and cin <= 4
 
@@ -185,13 +193,20 @@ def conv2d(x, layer, relu=False, out=None):
             return out
         return y
     op = _Operands(x, layer)
+    stride = _stride_of(layer)[0]
+    Ho, Wo = (op.H - 1) // stride + 1, (op.W - 1) // stride + 1
     if out is None:
-        out = torch.empty((op.B, op.cout, op.H, op.W), device=op.device, dtype=torch.float32)
-    elif not _dense(out) or out.dtype != torch.float32 or tuple(out.shape) != (op.B, op.cout, op.H, op.W):
+        out = torch.empty((op.B, op.cout, Ho, Wo), device=op.device, dtype=torch.float32)
+    elif not _dense(out) or out.dtype != torch.float32 or tuple(out.shape) != (op.B, op.cout, Ho, Wo):
         raise ValueError("conv2d(out=...) must be a dense-per-batch fp32 tensor of the result shape")
-    rc = _ffi.lib().dkt_conv2d_f16s(*op.head(), out.data_ptr(), out.stride(0), op.B, op.H, op.W, op.cout,
-                                    op.kh, op.kw, int(bool(relu)), _PASSES[_BACKEND],
-                                    _ffi.device_of(out), _ffi.stream_of(out))
+    if stride == 1:
+        rc = _ffi.lib().dkt_conv2d_f16s(*op.head(), out.data_ptr(), out.stride(0), op.B, op.H, op.W, op.cout,
+                                        op.kh, op.kw, int(bool(relu)), _PASSES[_BACKEND],
+                                        _ffi.device_of(out), _ffi.stream_of(out))
+    else:
+        rc = _ffi.lib().dkt_conv2d_f16s_strided(*op.head(), out.data_ptr(), out.stride(0), op.B, op.H, op.W, op.cout,
+                                                op.kh, op.kw, stride, int(bool(relu)), _PASSES[_BACKEND],
+                                                _ffi.device_of(out), _ffi.stream_of(out))
     _ffi.check(rc, "dkt_conv2d_f16s")
     return out
 

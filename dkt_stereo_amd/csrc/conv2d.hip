@@ -77,6 +77,7 @@ struct ConvArgs {
     float *out;
     long out_bs;
     int H, W, Cout, CoutPad, nch16, tiles_w;
+    int Ho, Wo;                        // output size (== H, W for stride 1)
     int tiles_xy, n_co, total_tiles;   // persistent tile stream: id = (b*n_co + co block)*tiles_xy + xy
     int relu;
     // fused ConvGRU gate epilogues (core/update.py:27-31), epi = 0 none;
@@ -114,12 +115,16 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1>
 __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int HALO = KS / 2;
     constexpr int TR = NF * WN;              // output rows per block
-    constexpr int PR = TR + 2 * HALO;        // patch rows
-    constexpr int PC = 32 + 2 * HALO;        // patch cols
+    // ST = 2: stride-2 convolution (the encoders' down-sampling layers).  Tiles are OUTPUT tiles;
+    // the input patch is (TR-1)*ST + KS rows x 31*ST + KS columns, and the fragment of tap
+    // (dy,dx) reads patch pixel (ST*row + dy, ST*col + dx): a lane stride of ST*80 B, still
+    // conflict-free for ds_read_b128 (8 consecutive lanes hit 8 disjoint 4-bank groups).
+    constexpr int PR = (TR - 1) * ST + KS;   // patch rows
+    constexpr int PC = 31 * ST + KS;         // patch cols
     constexpr int NPP = PR * PC;             // patch pixels
     constexpr int PITCH = 20;                // 32-bit words per pixel: 16 (32 fp16) + 4 pad
     constexpr int PLANE = NPP * PITCH;       // words per (hi or lo) plane
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
         for (int it = 0; it < SIT; ++it) {
             const int pp = lane + 64 * it;
             const int pr = pp / PC, pc = pp - pr * PC;
-            const int ih = th0 - HALO + pr, iw = tw0 - HALO + pc;
+            const int ih = th0 * ST - HALO + pr, iw = tw0 * ST - HALO + pc;
             sok[it] = pp < NPP && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
             spix[it] = sok[it] ? (unsigned)(ih * a.W + iw) * 4u : 0u;
         }
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
         const int dy = tap / KS, dx = tap % KS;
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
-            const int pp = (wn * NF + n + dy) * PC + li + dx;
+            const int pp = ((wn * NF + n) * ST + dy) * PC + li * ST + dx;
             const unsigned *pb = buf + pp * PITCH + kh * 8 + kg * 4;
             Bhi[slot][n] = *(const f16x8 *)pb;
             if (NPLANES == 2) Blo[slot][n] = *(const f16x8 *)(pb + PLANE);
@@ -326,12 +331,13 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
         const bool all_co = co_w + 32 * MF <= a.Cout;            // wave-uniform: no channel guard needed
         const int iHW = (int)HW;
         if (a.epi == 0) {
-            float *ob = a.out + (long)b * a.out_bs + (long)co_lane * HW;
+            const int oHW = a.Ho * a.Wo;                    // output plane (== HW when ST == 1)
+            float *ob = a.out + (long)b * a.out_bs + (long)co_lane * oHW;
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
                 const int oh = h0 + wn * NF + n, ow = w0 + li;
-                if (oh >= a.H || ow >= a.W) continue;
-                float *op = ob + (long)oh * a.W + ow;
+                if (oh >= a.Ho || ow >= a.Wo) continue;
+                float *op = ob + (long)oh * a.Wo + ow;
 #pragma unroll
                 for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
                         const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
                         float v = acc[m][n][r] * a.out_scale + bv[m][r];
                         if (a.relu) v = fmaxf(v, 0.0f);
-                        if (all_co || co_lane + dco < a.Cout) op[dco * iHW] = v;
+                        if (all_co || co_lane + dco < a.Cout) op[dco * oHW] = v;
                     }
             }
             return;
@@ -553,13 +559,12 @@ static int conv_slots(const void *kern, size_t lds, int dev) {
     return per_cu * cus;
 }
 
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1>
 static int launch_conv(ConvArgs a, int B, hipStream_t st) {
-    constexpr int HALO = KS / 2;
-    constexpr int NPP = (NF * WN + 2 * HALO) * (32 + 2 * HALO);
+    constexpr int NPP = ((NF * WN - 1) * ST + KS) * (31 * ST + KS);
     constexpr int STAGE = NPP * 20 * (PASSES == 3 ? 2 : 1);
     const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);   // + dummy words for surplus staging lanes
-    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF>;
+    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF, ST>;
     // once per device and instantiation (and never inside a stream capture after warm-up)
     static int slots[64] = {0};                        // benign race: worst case computed twice
     int dev = 0;
@@ -571,7 +576,7 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
         }
         slots[dev & 63] = conv_slots((const void *)kern, lds, dev);
     }
-    const int tiles_h = (a.H + NF * WN - 1) / (NF * WN);
+    const int tiles_h = (a.Ho + NF * WN - 1) / (NF * WN);
     a.tiles_xy = a.tiles_w * tiles_h;
     a.n_co = (a.Cout + 32 * MF * WM - 1) / (32 * MF * WM);
     const long total = (long)a.tiles_xy * a.n_co * B;
@@ -624,6 +629,14 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);                              // 256 co x 2 rows
 }
 
+// Stride-2 layers (the encoders' down-sampling convolutions, core/extractor.py:16,34,136-138):
+// 2-row output tiles keep the (2*TR+1) x 65 input patch at 52 KB per LDS stage.
+template <int KS, int PASSES>
+static int launch_conv_stride2(const ConvArgs &a, int B, hipStream_t st) {
+    if (a.Cout <= 128) return launch_conv<KS, 2, 2, 1, PASSES, CONV_ABL, 2, 2>(a, B, st);   // 128 co x 2 rows
+    return launch_conv<KS, 4, 1, 1, PASSES, CONV_ABL, 2, 2>(a, B, st);                      // 256 co x 1 row
+}
+
 struct ConvEpilogue {
     int kind;
     const float *c0, *c1, *h;
@@ -636,8 +649,9 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
                             int nsrc, const void *w_hi, const void *w_lo, const float *bias,
                             float out_scale, float *out, long out_bstride,
                             int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
-                            const ConvEpilogue *epi, int device, void *stream) {
+                            const ConvEpilogue *epi, int device, void *stream, int stride = 1) {
     if (!src || !src_channels || !src_bstride || !w_hi || !w_lo || !out) return DKT_E_NULL;
+    if (stride != 1 && (stride != 2 || epi)) return DKT_E_UNSUPPORTED;
     if (nsrc < 1 || nsrc > CONV_MAX_SRC || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || B > 65535) return DKT_E_SHAPE;
     if (KH != KW || (KH != 1 && KH != 3)) return DKT_E_UNSUPPORTED;
     if (passes < 1 || passes > 3) return DKT_E_UNSUPPORTED;
@@ -656,9 +670,12 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
     a.out = out;
     a.out_bs = out_bstride;
     a.H = H; a.W = W; a.Cout = Cout;
+    // "same"-style padding KH/2 (what every layer on the path uses): output = floor((H - 1) / stride) + 1
+    a.Ho = (H - 1) / stride + 1;
+    a.Wo = (W - 1) / stride + 1;
     a.CoutPad = conv_cout_pad(Cout);
     a.nch16 = conv_padded_channels(src_channels, nsrc) / 16;
-    a.tiles_w = (W + 31) / 32;
+    a.tiles_w = (a.Wo + 31) / 32;
     a.relu = relu ? 1 : 0;
     a.epi = 0;
     a.e_c0 = a.e_c1 = a.e_h = nullptr;
@@ -673,6 +690,16 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
     }
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
+    if (stride == 2) {
+        if (KH == 3) {
+            if (passes == 3) return launch_conv_stride2<3, 3>(a, B, st);
+            if (passes == 2) return launch_conv_stride2<3, 2>(a, B, st);
+            return launch_conv_stride2<3, 1>(a, B, st);
+        }
+        if (passes == 3) return launch_conv_stride2<1, 3>(a, B, st);
+        if (passes == 2) return launch_conv_stride2<1, 2>(a, B, st);
+        return launch_conv_stride2<1, 1>(a, B, st);
+    }
     if (KH == 3) {
         if (passes == 3) return launch_conv_shape<3, 3>(a, B, st);
         if (passes == 2) return launch_conv_shape<3, 2>(a, B, st);
@@ -690,6 +717,15 @@ extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels,
                                int device, void *stream) {
     return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, out, out_bstride,
                             B, H, W, Cout, KH, KW, relu, passes, nullptr, device, stream);
+}
+
+extern "C" int dkt_conv2d_f16s_strided(const float *const *src, const int *src_channels, const long *src_bstride,
+                                       int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                                       float out_scale, float *out, long out_bstride,
+                                       int B, int H, int W, int Cout, int KH, int KW, int stride, int relu,
+                                       int passes, int device, void *stream) {
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, out, out_bstride,
+                            B, H, W, Cout, KH, KW, relu, passes, nullptr, device, stream, stride);
 }
 
 extern "C" int dkt_conv2d_f16s_gate_zr(const float *const *src, const int *src_channels, const long *src_bstride,

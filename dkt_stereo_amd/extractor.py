@@ -78,11 +78,7 @@ def conv_norm_act(conv, norm, x, relu):
     if (isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats
             and isinstance(conv, _Conv2d) and _hip_ok(x) and conv.dilation == (1, 1) and conv.groups == 1
             and not (torch.is_grad_enabled() and conv.weight.requires_grad)):
-        f = _folded(conv, norm)
-        if conv.stride == (1, 1):
-            return conv2d(x, f, relu=relu)
-        y = F.conv2d(x, f.weight, f.bias, stride=conv.stride, padding=conv.padding)
-        return torch.relu_(y) if relu else y
+        return conv2d(x, _folded(conv, norm), relu=relu)      # conv2d honours f.stride
     return norm_act(norm, conv(x), relu)
 
 
@@ -103,7 +99,7 @@ class _Conv2d(nn.Conv2d):
     update block uses; everything else (stride 2, 7x7 stem, autograd, CPU) is plain torch."""
 
     def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and self.stride == (1, 1) and self.dilation == (1, 1)
+        if (x.is_cuda and x.dtype == torch.float32 and self.stride in ((1, 1), (2, 2)) and self.dilation == (1, 1)
                 and self.groups == 1 and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
             return conv2d(x, self)
         return super().forward(x)

@@ -241,6 +241,15 @@ int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long
                     float *out, long out_bstride, int B, int H, int W, int Cout, int KH, int KW,
                     int relu, int passes, int device, void *stream);
 
+/* dkt_conv2d_f16s with a stride (1 or 2) and padding K/2: the down-sampling convolutions of the
+ * encoders (core/extractor.py:16,34: 3x3 stride 2 and the 1x1 stride-2 projection).  H, W are the
+ * INPUT size; out is (B, Cout, (H-1)/stride+1, (W-1)/stride+1). */
+int dkt_conv2d_f16s_strided(const float *const *src, const int *src_channels, const long *src_bstride,
+                            int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                            float out_scale, float *out, long out_bstride,
+                            int B, int H, int W, int Cout, int KH, int KW, int stride, int relu,
+                            int passes, int device, void *stream);
+
 /* ConvGRU with the gate arithmetic fused into the convolution epilogues (core/update.py:23-32):
  * no z|r / q pre-activation tensors ever reach HBM.
  *   gate_zr : merged convz|convr over [h | x...] (2*Ch outputs, packed as one layer):

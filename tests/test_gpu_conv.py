@@ -95,6 +95,29 @@ def test_direct_conv_vs_fp64(shape):
     assert float((got.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [("s2_k3", 2, 64, 96, 23, 70, 3), ("s2_k3_odd", 1, 96, 128, 9, 33, 3),
+                                   ("s2_k1", 2, 64, 96, 12, 41, 1), ("s2_k3_wide", 1, 32, 160, 8, 64, 3),
+                                   ("s2_k3_tiny", 1, 8, 24, 1, 1, 3), ("s2_k1_big", 1, 128, 128, 46, 78, 1)],
+                         ids=lambda s: s[0])
+@torch.no_grad()
+def test_strided_conv_vs_fp64(shape):
+    """dkt_conv2d_f16s_strided (stride 2, padding K/2): the encoders' down-sampling convolutions
+    (core/extractor.py:16,34), incl. odd sizes and ReLU, against an fp64 convolution."""
+    from dkt_stereo_amd import conv
+    name, B, cin, cout, H, W, k = shape
+    conv.set_backend("f16x3")
+    torch.manual_seed(77)
+    layer = torch.nn.Conv2d(cin, cout, k, stride=2, padding=k // 2).to(DEV)
+    assert conv.hip_eligible(layer)
+    x = G(_synth.normal((B, cin, H, W), 96, name, scale=1.5))
+    for relu in (False, True):
+        ref = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), stride=2, padding=k // 2)
+        ref = ref.clamp_min(0) if relu else ref
+        got = conv.conv2d(x, layer, relu=relu)
+        assert got.shape == ref.shape
+        assert float((got.double() - ref).abs().max()) <= 3e-6 * max(1.0, float(ref.abs().max()))
+
+
 @torch.no_grad()
 def test_conv_weight_cache_invalidation():
     from dkt_stereo_amd import conv
