@@ -134,6 +134,54 @@ class RAFTStereo(nn.Module):
                 dst.copy_(src)
         return up_mask
 
+    #: software-pipeline the GRU stack across iterations (DKT_PIPELINE_GRUS=0 disables): gru16 of
+    #: this iteration and gru32 of the NEXT one run on a second stream beside lookup + motion
+    #: encoder + gru08 + flow head.  Every GRU still sees exactly the inputs the reference's
+    #: sequential order gives it (gru32(i+1) needs only net[2](i), net[1](i)): bit-identical.
+    pipeline_grus = os.environ.get("DKT_PIPELINE_GRUS", "1") != "0"
+
+    def _can_pipeline(self):
+        a = self.args
+        return (self.pipeline_grus and a.n_gru_layers == 3 and not a.slow_fast_gru
+                and self.update_block.side_stream)
+
+    def _one_iteration_pipelined(self, corr_fn, coords0, coords1, net_state, inp_list, need_mask, last):
+        """raft_stereo.py:146-167 with the two coarse GRUs off the critical path.  Precondition:
+        net_state[2] already holds gru32 of THIS iteration (prologue / previous call); unless
+        `last`, gru32 of the next iteration is computed here.  Updates coords1 / net_state in place."""
+        ub = self.update_block
+        dev = coords1.device
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        nets = list(net_state)
+        ub.inplace_state = True
+        saved_side = ub.side_stream
+        ub.side_stream = False                       # the fork/join is done here
+        done16 = torch.cuda.Event()
+        try:
+            side.wait_stream(main)                   # fork
+            with torch.cuda.stream(side):
+                ub(nets, inp_list, iter32=False, iter16=True, iter08=False, update=False)      # gru16(i)
+                done16.record(side)
+                if not last:
+                    ub(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)  # gru32(i+1)
+            corr = corr_fn(coords1)
+            flow = coords1 - coords0
+            ub.before_fine = lambda: main.wait_event(done16)
+            nets, up_mask, delta_flow = ub(nets, inp_list, corr, flow, iter32=False, iter16=False,
+                                           need_mask=need_mask)
+            main.wait_stream(side)                   # join
+        finally:
+            ub.before_fine = None
+            ub.side_stream = saved_side
+            ub.inplace_state = False
+        delta_flow[:, 1] = 0.0          # stereo: project onto the epipolar line
+        coords1.add_(delta_flow)
+        for dst, src in zip(net_state, nets):
+            if dst is not src:
+                dst.copy_(src)
+        return up_mask
+
     def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init):
         """Same arithmetic as the eager loop; iterations 2..iters-1 are replays of one
         captured HIP graph (~60 launches per iteration leave the CPU out of the loop)."""
@@ -160,8 +208,19 @@ class RAFTStereo(nn.Module):
                     dst.copy_(src)
         if flow_init is not None:
             st["coords1"].add_(flow_init)
-        step = lambda mask: self._one_iteration(st["corr"], st["coords0"], st["coords1"],  # noqa: E731
-                                                st["net"], st["inp"], mask)
+        if self._can_pipeline():
+            # prologue: gru32 of iteration 0 (the reference runs it first in every iteration)
+            ub = self.update_block
+            ub.inplace_state = True
+            try:
+                ub(list(st["net"]), st["inp"], iter32=True, iter16=False, iter08=False, update=False)
+            finally:
+                ub.inplace_state = False
+            step = lambda mask: self._one_iteration_pipelined(st["corr"], st["coords0"], st["coords1"],  # noqa: E731
+                                                              st["net"], st["inp"], mask, last=mask)
+        else:
+            step = lambda mask: self._one_iteration(st["corr"], st["coords0"], st["coords1"],  # noqa: E731
+                                                    st["net"], st["inp"], mask)
         done = 0
         if st["graph"] is None:
             step(False)                      # eager once: packs weights, sizes the allocator

@@ -237,6 +237,8 @@ class BasicMultiUpdateBlock(nn.Module):
     inplace_state = False
     #: run the motion encoder concurrently with gru32/gru16 on a second stream (DKT_SIDE_STREAM=0 disables)
     side_stream = os.environ.get("DKT_SIDE_STREAM", "1") != "0"
+    #: harness hook called between the motion encoder and the finest GRU (see RAFTStereo._one_iteration_pipelined)
+    before_fine = None
 
     def _gru_stack(self, net, inp, fine, mid, coarse, motion, it_fine, it_mid, it_coarse):
         n = self.args.n_gru_layers
@@ -264,6 +266,8 @@ class BasicMultiUpdateBlock(nn.Module):
                 main.wait_stream(side)          # join: gru08 consumes the motion features
             else:
                 mf = motion()
+            if self.before_fine is not None:
+                self.before_fine()              # harness hook: wait for a coarse GRU running on another stream
             if n > 1:
                 net[0] = fine(net[0], *(inp[0]), mf, interp(net[1], net[0]), out=o(net[0]))
             else:
