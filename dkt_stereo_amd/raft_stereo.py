@@ -139,6 +139,9 @@ class RAFTStereo(nn.Module):
     #: encoder + gru08 + flow head.  Every GRU still sees exactly the inputs the reference's
     #: sequential order gives it (gru32(i+1) needs only net[2](i), net[1](i)): bit-identical.
     pipeline_grus = os.environ.get("DKT_PIPELINE_GRUS", "1") != "0"
+    #: with the pipelined schedule: the motion encoder's flow branch on a third stream.  Opt-in
+    #: (DKT_BRANCH_STREAMS=1): measured gain 0.3 ms per pair, not worth a third capture branch by default
+    branch_streams = os.environ.get("DKT_BRANCH_STREAMS", "0") == "1"
 
     def _can_pipeline(self):
         a = self.args
@@ -157,6 +160,7 @@ class RAFTStereo(nn.Module):
         ub.inplace_state = True
         saved_side = ub.side_stream
         ub.side_stream = False                       # the fork/join is done here
+        ub.encoder.branch_streams = self.branch_streams   # the encoder runs on `main`: its fork is not nested
         done16 = torch.cuda.Event()
         try:
             side.wait_stream(main)                   # fork
@@ -173,6 +177,7 @@ class RAFTStereo(nn.Module):
             main.wait_stream(side)                   # join
         finally:
             ub.before_fine = None
+            ub.encoder.branch_streams = False
             ub.side_stream = saved_side
             ub.inplace_state = False
         delta_flow[:, 1] = 0.0          # stereo: project onto the epipolar line

@@ -149,10 +149,25 @@ class BasicMotionEncoder(nn.Module):
         setattr(self, self._branch[1], nn.Conv2d(64, 64, 3, padding=1))
         self.conv = nn.Conv2d(64 + 64, 128 - self._aux_ch, 3, padding=1)
 
+    #: harness switch: run the flow branch on its own stream beside the correlation branch.  Only
+    #: set when the encoder itself runs on the capture's origin stream (a fork nested inside
+    #: another forked stream crashed hipStreamEndCapture on ROCm 7.2).
+    branch_streams = False
+
     def forward(self, flow, corr):
-        cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
-        flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
-                     getattr(self, self._branch[1]), relu=True)
+        if self.branch_streams and flow.is_cuda:
+            cur = torch.cuda.current_stream(flow.device)
+            aux = _side_stream(flow.device, slot=1)
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
+                             getattr(self, self._branch[1]), relu=True)
+            cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
+            cur.wait_stream(aux)
+        else:
+            cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
+            flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
+                         getattr(self, self._branch[1]), relu=True)
         # [conv output (126/127 ch) | flow]: the convolution writes straight into the first
         # channels of the 128-channel motion-feature buffer (no torch.cat of the big part)
         B, _, H, W = flow.shape
@@ -200,11 +215,14 @@ def interp(x, dest):
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def _side_stream(device, slot=0):
+    """Per-device auxiliary HIP streams (slot 0: coarse GRUs / motion encoder / fnet; slot 1: the
+    flow branch of the motion encoder)."""
+    idx = torch.device(device).index
+    key = (idx if idx is not None else torch.cuda.current_device(), slot)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
     return st
 
 
