@@ -115,7 +115,7 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
 __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int HALO = KS / 2;
     constexpr int TR = NF * WN;              // output rows per block
@@ -126,11 +126,13 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
     constexpr int PR = (TR - 1) * ST + KS;   // patch rows
     constexpr int PC = 31 * ST + KS;         // patch cols
     constexpr int NPP = PR * PC;             // patch pixels
-    constexpr int PITCH = 20;                // 32-bit words per pixel: 16 (32 fp16) + 4 pad
+    // CK = k16 steps per tap and chunk: a chunk is 16*CK input channels.  CK = 1 halves the LDS
+    // stage, which lets the 64-channel layers use 8-row tiles (NF = 2) at two blocks per CU.
+    constexpr int PITCH = 8 * CK + 4;        // 32-bit words per pixel: 8*CK (16*CK fp16) + 4 pad
     constexpr int PLANE = NPP * PITCH;       // words per (hi or lo) plane
     constexpr int NPLANES = PASSES == 3 ? 2 : 1;   // x_lo is only needed for the w_hi*x_lo pass
     constexpr int STAGE = PLANE * NPLANES;
-    constexpr int NSTEP = KS * KS * 2;       // (tap, 16-channel half) steps per chunk
+    constexpr int NSTEP = KS * KS * CK;      // (tap, 16-channel group) steps per chunk
     // weight-fragment ring (prefetch distance AR-1 steps).  A step of an NF=1 tile is only
     // 6 MFMAs (~80 ns): its ring is deeper so that the L2 latency of the weights stays covered.
     constexpr int AR_WANT = NF == 1 ? CONV_AR_NF1 : CONV_AR;
@@ -167,9 +169,12 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
     // pixel's 8 channels as one ds_write_b128 per plane.  Both halves take a SLICE range
     // (slice = pixel slot x channel pair) so that they can be spread over the MFMA steps of the
     // previous chunk.
-    constexpr int SIT = (NPP + 63) / 64;      // pixel slots per lane
+    constexpr int SG = 2 * CK;                // waves along channels (8 channels each)
+    constexpr int PG = 4 / SG;                // waves along pixels
+    constexpr int SIT = (NPP + 64 * PG - 1) / (64 * PG);   // pixel slots per lane
     constexpr int NSL = SIT * 4;              // slices per chunk
-    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const int swave = __builtin_amdgcn_readfirstlane(wave) % SG;     // channel group this wave stages
+    const int spgrp = __builtin_amdgcn_readfirstlane(wave) / SG;     // pixel group
     unsigned spix[SIT];                       // byte offset of the slot's pixel inside a channel plane
     bool sok[SIT];                            // the slot's pixel lies inside the image
     float sreg[SIT][8];
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
     auto stage_tile = [&](int th0, int tw0) {
 #pragma unroll
         for (int it = 0; it < SIT; ++it) {
-            const int pp = lane + 64 * it;
+            const int pp = lane + 64 * (it * PG + spgrp);
             const int pr = pp / PC, pc = pp - pr * PC;
             const int ih = th0 * ST - HALO + pr, iw = tw0 * ST - HALO + pc;
             sok[it] = pp < NPP && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
         }
     };
     auto stage_select = [&](int tb, int chunk) {
-        int s = 0, c0 = chunk * 32;
+        int s = 0, c0 = chunk * 16 * CK;
         while (s + 1 < a.nsrc && c0 >= ((a.src_ch[s] + 31) & ~31)) {
             c0 -= (a.src_ch[s] + 31) & ~31;
             ++s;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
             shw[it][q] = pack_h2(h0_, h1_);
             if (NPLANES == 2) slw[it][q] = pack_h2((_Float16)(x0 - (float)h0_), (_Float16)(x1 - (float)h1_));
             if (q == 3) {
-                const int pp = lane + 64 * it;
+                const int pp = lane + 64 * (it * PG + spgrp);
                 unsigned *dst = pp < NPP ? buf + pp * PITCH + 4 * swave : lds + 2 * STAGE;   // surplus lanes -> dummy
                 *(uint4 *)dst = make_uint4(shw[it][0], shw[it][1], shw[it][2], shw[it][3]);
                 if (NPLANES == 2)
@@ -255,13 +260,13 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
     };
     long wl_cur = wlane_of(co_blk), wl_nxt = wl_cur;   // weight bases of the computed / the following tile
     const long wstep = (long)a.CoutPad * 16;           // one 16-channel slab
-    const int nchunks = a.nch16 / 2;
+    const int nchunks = a.nch16 / CK;
 
     f16x8 Ahi[AR][MF], Alo[AR][MF];
     f16x8 Bhi[2][NF], Blo[2][NF];
     auto loadA = [&](int slot, long wlane, int chunk, int step) {
-        const int tap = step >> 1, kh = step & 1;
-        const long wbase = ((long)tap * a.nch16 + (chunk * 2 + kh)) * wstep + wlane;
+        const int tap = step / CK, kh = step % CK;
+        const long wbase = ((long)tap * a.nch16 + (chunk * CK + kh)) * wstep + wlane;
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
             Ahi[slot][m] = *(const f16x8 *)(a.whi + wbase + m * 32 * 16);
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
         }
     };
     auto loadB = [&](int slot, const unsigned *buf, int step) {
-        const int tap = step >> 1, kh = step & 1;
+        const int tap = step / CK, kh = step % CK;
         const int dy = tap / KS, dx = tap % KS;
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
-            if (more && !(ABL & 2)) loadB(0, nxt, 0);      // NSTEP is even: step 0 always uses B slot 0
+            if (more && !(ABL & 2)) loadB(0, nxt, 0);      // step 0 always uses B slot 0
         }
         epilogue();
         if (!have_next) break;
@@ -559,12 +564,12 @@ static int conv_slots(const void *kern, size_t lds, int dev) {
     return per_cu * cus;
 }
 
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
 static int launch_conv(ConvArgs a, int B, hipStream_t st) {
     constexpr int NPP = ((NF * WN - 1) * ST + KS) * (31 * ST + KS);
-    constexpr int STAGE = NPP * 20 * (PASSES == 3 ? 2 : 1);
+    constexpr int STAGE = NPP * (8 * CK + 4) * (PASSES == 3 ? 2 : 1);
     const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);   // + dummy words for surplus staging lanes
-    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF, ST>;
+    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF, ST, CK>;
     // once per device and instantiation (and never inside a stream capture after warm-up)
     static int slots[64] = {0};                        // benign race: worst case computed twice
     int dev = 0;
@@ -602,22 +607,31 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     }();
     switch (forced) {
     case 1: return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);
+    case 2: return launch_conv<KS, 1, 4, 2, PASSES>(a, B, st);
     case 3: return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);
     case 5: return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);
     case 6: return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);
     case 7: return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);
     case 8: return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st);
+    case 9: if constexpr (KS == 3) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st); break;
     default: break;
     }
     // 4-row blocks keep the LDS stage at 65 KB, i.e. two blocks per CU; the 8-row forms
     // (one block per CU) measured 15-35 % slower on every encoder layer (tools/_exp_enc.py).
     // Small images (the 1/8 and 1/16 GRUs: 115 and 69 tiles of the default shape for 256 CUs)
     // take half-height tiles so that twice as many CUs work.
-    (void)tiles4;
     const long few = CONV_FEW_TILES;
     // the flow / disparity heads (2 and 1 output channels): a 32-channel wave tile halves the padded MFMA work
     if (a.Cout <= 32) return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st);  // 32 co x 4 rows
-    if (a.Cout <= 64) return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);            // 64 co x 4 rows
+    if (a.Cout <= 64) {
+        // 64 co x 8 rows with 16-channel chunks (33 KB LDS stage: still two blocks per CU): twice the
+        // MFMAs per weight fragment of the 4-row form (64->64 @368x624: 90 -> 78 us; not for images
+        // that give fewer 8-row tiles than resident blocks: @184x312 29 -> 32 us)
+        if constexpr (KS == 3) {
+            if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st);   // >= one full wave of blocks
+        }
+        return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);                          // 64 co x 4 rows
+    }
     if (a.Cout <= 128) {
         if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);        // 128 co x 2 rows
         return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);                          // 128 co x 4 rows
