@@ -116,7 +116,7 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
 template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
-__global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) void conv2d_f16s_kernel(ConvArgs a) {
     constexpr int HALO = KS / 2;
     constexpr int TR = NF * WN;              // output rows per block
     // ST = 2: stride-2 convolution (the encoders' down-sampling layers).  Tiles are OUTPUT tiles;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, CONV_MIN_BLOCKS) void conv2d_f16s_kernel(ConvA
     // (slice = pixel slot x channel pair) so that they can be spread over the MFMA steps of the
     // previous chunk.
     constexpr int SG = 2 * CK;                // waves along channels (8 channels each)
-    constexpr int PG = 4 / SG;                // waves along pixels
+    constexpr int PG = WM * WN / SG;          // waves along pixels
     constexpr int SIT = (NPP + 64 * PG - 1) / (64 * PG);   // pixel slots per lane
     constexpr int NSL = SIT * 4;              // slices per chunk
     const int swave = __builtin_amdgcn_readfirstlane(wave) % SG;     // channel group this wave stages
@@ -557,9 +557,9 @@ extern "C" int dkt_conv2d_pack_weights(const float *w, const int *src_channels, 
 }
 
 // Resident blocks the device holds of one instantiation (occupancy x CUs), cached per device.
-static int conv_slots(const void *kern, size_t lds, int dev) {
+static int conv_slots(const void *kern, size_t lds, int dev, int threads) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     return per_cu * cus;
 }
@@ -579,7 +579,7 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        slots[dev & 63] = conv_slots((const void *)kern, lds, dev);
+        slots[dev & 63] = conv_slots((const void *)kern, lds, dev, 64 * WM * WN);
     }
     const int tiles_h = (a.Ho + NF * WN - 1) / (NF * WN);
     a.tiles_xy = a.tiles_w * tiles_h;
@@ -590,7 +590,7 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
     // DKT_CONV_PERSIST=0 (tuning knob): one block per tile, i.e. no cross-tile pipelining
     static const bool persist = [] { const char *e = getenv("DKT_CONV_PERSIST"); return !e || atoi(e) != 0; }();
     const long nblk = persist && total > slots[dev & 63] ? slots[dev & 63] : total;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, a);
     return dkt_launch_status();
 }
 
@@ -613,6 +613,7 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     case 6: return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);
     case 7: return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);
     case 8: return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st);
+    case 10: if constexpr (KS == 3) return launch_conv<KS, 4, 2, 2, PASSES>(a, B, st); break;
     case 9: if constexpr (KS == 3) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st); break;
     default: break;
     }
@@ -638,7 +639,13 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     }
     const long tiles2 = (long)a.tiles_w * ((a.H + 1) / 2) * B * ((a.Cout + 255) / 256);
     if (tiles2 < few) return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);            // 256 co x 1 row
-    // wide layers: 256 co x 2 rows per block, two blocks per CU.  (Measured on 384->256 @184x312:
+    // wide layers on large images: ONE block of 8 waves per CU, 256 co x 4 rows (WM x WN = 4 x 2): the two
+    // waves of a SIMD share their weight fragments through L1 and the patch halo shrinks (6 rows
+    // staged per 4 instead of 4 per 2).  Measured 384->256 @184x312: 326 -> 315 us; 128->256: 113 -> 109.
+    if (tiles4 * ((a.Cout + 255) / 256) >= 256) {
+        if constexpr (KS == 3) return launch_conv<KS, 4, 2, 2, PASSES>(a, B, st);
+    }
+    // otherwise: 256 co x 2 rows per block, two blocks per CU.  (Measured on 384->256 @184x312:
     // 324 us vs 374 us for the 256 co x 4 rows / one-block-per-CU form.)
     return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);                              // 256 co x 2 rows
 }
