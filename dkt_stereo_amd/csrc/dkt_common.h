@@ -68,6 +68,25 @@ __device__ __forceinline__ DktTap dkt_tap(float x, float wm1, float half_wm1) {
     return t;
 }
 
+// dkt_tap with the IEEE division 2x / (W-1) evaluated as two Newton corrections on the host-rounded
+// reciprocal inv = RN(1/(W-1)):  q0 = a*inv;  q1 = q0 + (a - b*q0)*inv (faithful);
+// q2 = q1 + (a - b*q1)*inv (correctly rounded, Markstein) -- 5 instructions instead of the ~10 of
+// v_div_scale / v_div_fmas / v_div_fixup.  Bit-identical to dkt_tap (tests/test_gpu_parity.py compares
+// ~10^8 coordinates per width); callers keep dkt_tap for W == 1 (division by zero).
+__device__ __forceinline__ DktTap dkt_tap_rcp(float x, float wm1, float inv, float half_wm1) {
+    const float a2 = __fmul_rn(2.0f, x);
+    float q = __fmul_rn(a2, inv);
+    q = __fmaf_rn(__fmaf_rn(-wm1, q, a2), inv, q);
+    q = __fmaf_rn(__fmaf_rn(-wm1, q, a2), inv, q);
+    const float xg = __fsub_rn(q, 1.0f);
+    const float ix = __fmul_rn(__fadd_rn(xg, 1.0f), half_wm1);
+    DktTap t;
+    t.fl = floorf(ix);
+    t.w = __fsub_rn(ix, t.fl);
+    t.e = __fsub_rn(1.0f, t.w);
+    return t;
+}
+
 __device__ __forceinline__ float dkt_blend(float v0, float v1, const DktTap &t) {
     return __fmaf_rn(v1, t.w, __fmul_rn(v0, t.e));
 }

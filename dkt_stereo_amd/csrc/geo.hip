@@ -16,51 +16,73 @@ struct GeoArgs {
     const float *coords;
     float *out;
     long HW;
-    int C, D, W2, L;
+    int C, D, W2, L, ngrp;
+    float inv_d[DKT_MAX_LEVELS];   // RN(1 / ((D>>i) - 1)), host-computed
+    float inv_w[DKT_MAX_LEVELS];   // RN(1 / ((W2>>i) - 1))
 };
 
 __device__ __forceinline__ int geo_clamp_idx(float fl, int W) {
     return (int)fminf(fmaxf(fl, -2.0f), (float)W + 1.0f);
 }
 
+// thread = (pixel, level, channel group).  The 2r+1 taps along D depend on the pixel's disparity
+// only, so a thread computes them once (reciprocal-based exact division, dkt_tap_rcp) and applies
+// them to GEO_GC channels of the geometry volume; the last group of a level is the init-correlation
+// row (its own taps).  The first form had one thread per channel: 8x the tap arithmetic, 23 % of HBM.
+#define GEO_GC 4
 template <int R>
 __global__ __launch_bounds__(256) void geo_lookup_kernel(GeoArgs a) {
     constexpr int K = 2 * R + 1;
     const long p = blockIdx.x * 256L + threadIdx.x;
     if (p >= a.HW) return;
-    const int lv = blockIdx.y / (a.C + 1);
-    const int c = blockIdx.y % (a.C + 1);
+    const int lv = blockIdx.y / (a.ngrp + 1);
+    const int grp = blockIdx.y % (a.ngrp + 1);
     const int b = blockIdx.z;
     const size_t n = (size_t)b * a.HW + p;
     const float inv = (float)(1 << lv);
     const float dl = __fdiv_rn(a.disp[n], inv);
     const int per_level = K * (a.C + 1);
-    float *o = a.out + ((size_t)b * a.L * per_level + (size_t)lv * per_level + (size_t)c * K) * a.HW + p;
+    float *obase = a.out + ((size_t)b * a.L * per_level + (size_t)lv * per_level) * a.HW + p;
 
-    if (c < a.C) {
+    if (grp < a.ngrp) {
         // geometry volume: taps along D, plane stride HW
         const int di = a.D >> lv;
         const float wm1 = (float)(di - 1), hwm1 = __fdiv_rn(wm1, 2.0f);
-        const float *base = a.geo.p[lv] + ((size_t)b * a.C + c) * (size_t)di * a.HW + p;
         DktTap taps[K];
+        if (di > 1) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) taps[k] = dkt_tap(__fadd_rn((float)(k - R), dl), wm1, hwm1);
-        const int i0 = geo_clamp_idx(taps[0].fl, di);
-        float win[K + 1];
+            for (int k = 0; k < K; ++k) taps[k] = dkt_tap_rcp(__fadd_rn((float)(k - R), dl), wm1, a.inv_d[lv], hwm1);
+        } else {
 #pragma unroll
-        for (int j = 0; j <= K; ++j) {
-            const int d = i0 + j;
-            win[j] = (d >= 0 && d < di) ? base[(size_t)d * a.HW] : 0.0f;
+            for (int k = 0; k < K; ++k) taps[k] = dkt_tap(__fadd_rn((float)(k - R), dl), wm1, hwm1);
         }
+        const int i0 = geo_clamp_idx(taps[0].fl, di);
+        bool regular = true;                       // all taps inside the K+1 window (always, up to rounding)
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int ik = geo_clamp_idx(taps[k].fl, di);
-            float v0 = win[k], v1 = win[k + 1];
-            if (ik != i0 + k) {
-                v0 = (ik >= 0 && ik < di) ? base[(size_t)ik * a.HW] : 0.0f;
-                v1 = (ik + 1 >= 0 && ik + 1 < di) ? base[(size_t)(ik + 1) * a.HW] : 0.0f;
+        for (int k = 0; k < K; ++k) regular = regular && geo_clamp_idx(taps[k].fl, di) == i0 + k;
+        const int c0 = grp * GEO_GC;
+        for (int cc = 0; cc < GEO_GC && c0 + cc < a.C; ++cc) {
+            const int c = c0 + cc;
+            const float *base = a.geo.p[lv] + ((size_t)b * a.C + c) * (size_t)di * a.HW + p;
+            float *o = obase + (size_t)c * K * a.HW;
+            float win[K + 1];
+#pragma unroll
+            for (int j = 0; j <= K; ++j) {
+                const int d = i0 + j;
+                win[j] = (d >= 0 && d < di) ? base[(size_t)d * a.HW] : 0.0f;
             }
-            o[(size_t)k * a.HW] = dkt_blend(v0, v1, taps[k]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float v0 = win[k], v1 = win[k + 1];
+                if (!regular) {
+                    const int ik = geo_clamp_idx(taps[k].fl, di);
+                    if (ik != i0 + k) {
+                        v0 = (ik >= 0 && ik < di) ? base[(size_t)ik * a.HW] : 0.0f;
+                        v1 = (ik + 1 >= 0 && ik + 1 < di) ? base[(size_t)(ik + 1) * a.HW] : 0.0f;
+                    }
+                }
+                o[(size_t)k * a.HW] = dkt_blend(v0, v1, taps[k]);
+            }
         }
     } else {
         // init correlation row: x = (coords/2^i - disp/2^i) + dx   (geometry.py:50)
@@ -69,9 +91,15 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(GeoArgs a) {
         const float *row = a.init.p[lv] + n * (size_t)wi;
         const float cl = __fdiv_rn(a.coords[n], inv);
         const float xc = __fsub_rn(cl, dl);
+        float *o = obase + (size_t)a.C * K * a.HW;
         DktTap taps[K];
+        if (wi > 1) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) taps[k] = dkt_tap(__fadd_rn(xc, (float)(k - R)), wm1, hwm1);
+            for (int k = 0; k < K; ++k) taps[k] = dkt_tap_rcp(__fadd_rn(xc, (float)(k - R)), wm1, a.inv_w[lv], hwm1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) taps[k] = dkt_tap(__fadd_rn(xc, (float)(k - R)), wm1, hwm1);
+        }
         const int i0 = geo_clamp_idx(taps[0].fl, wi);
         float win[K + 1];
 #pragma unroll
@@ -94,7 +122,7 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(GeoArgs a) {
 
 template <int R>
 static void launch_geo(const GeoArgs &a, int B, hipStream_t st) {
-    dim3 grid((unsigned)((a.HW + 255) / 256), (unsigned)(a.L * (a.C + 1)), (unsigned)B);
+    dim3 grid((unsigned)((a.HW + 255) / 256), (unsigned)(a.L * (a.ngrp + 1)), (unsigned)B);
     hipLaunchKernelGGL(geo_lookup_kernel<R>, grid, dim3(256), 0, st, a);
 }
 
@@ -116,6 +144,12 @@ extern "C" int dkt_geo_lookup(const float *const *geo_pyr, const float *const *i
     DKT_ENTER(device);
     a.disp = disp; a.coords = coords; a.out = out;
     a.HW = (long)H * W; a.C = C; a.D = D; a.W2 = W2; a.L = L;
+    a.ngrp = (C + GEO_GC - 1) / GEO_GC;
+    for (int i = 0; i < DKT_MAX_LEVELS; ++i) {
+        const int di = i < L ? (D >> i) : 0, wi = i < L ? (W2 >> i) : 0;
+        a.inv_d[i] = di > 1 ? (float)(1.0 / (double)(di - 1)) : 0.0f;
+        a.inv_w[i] = wi > 1 ? (float)(1.0 / (double)(wi - 1)) : 0.0f;
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (r) {
         case 0: launch_geo<0>(a, B, st); break;

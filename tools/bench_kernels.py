@@ -267,7 +267,10 @@ def bench_volumes():
     fn = Combined_Geo_Encoding_Volume(m1, m2, geo, num_levels=2, radius=4)
     disp = torch.rand(1, 1, 184, 312, device=DEV) * 40
     coords = torch.arange(312, device=DEV).float().view(1, 1, 312, 1).repeat(1, 184, 1, 1)
-    report("geo_lookup IGEV cfg3", timeit(lambda: fn(disp, coords), n=50), bytes_=184 * 312 * 1376)
+    report("geo_lookup IGEV cfg3 (random per-pixel disparity)", timeit(lambda: fn(disp, coords), n=50), bytes_=184 * 312 * 1376)
+    xs = torch.arange(312, device=DEV).float().view(1, 1, 1, 312)
+    smooth = (8.0 + 24.0 * xs / 312 + 0.3 * torch.rand(1, 1, 184, 312, device=DEV)).contiguous()
+    report("geo_lookup IGEV cfg3 (smooth disparity)", timeit(lambda: fn(smooth, coords), n=50), bytes_=184 * 312 * 1376)
 
 
 def bench_next():
