@@ -20,6 +20,14 @@ def G(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
+def same(a, b):
+    """Bit-for-bit equality; a width-1 pyramid level makes the reference divide by W-1 = 0, and the
+    NaNs it then produces must appear in the same places."""
+    a = a.cpu().numpy() if torch.is_tensor(a) else a
+    b = b.cpu().numpy() if torch.is_tensor(b) else b
+    return np.array_equal(a, b, equal_nan=True)
+
+
 @settings(**SET)
 @given(B=st.integers(1, 3), C=st.integers(1, 40), H=st.integers(1, 5), W1=st.integers(2, 70), dW=st.integers(-8, 12),
        L=st.integers(1, 4), r=st.integers(0, 5), seed=st.integers(0, 10 ** 6))
@@ -41,8 +49,8 @@ def test_corr_block_random(c_oracle, B, C, H, W1, dW, L, r, seed):
     for i in range(1, L):
         assert np.array_equal(pyr[i], own[i])                              # pooling: bit exact
     out = blk(G(coords))
-    assert np.array_equal(out.cpu().numpy(), c_oracle.corr1d_lookup(pyr, coords, r))   # sampler: bit exact
-    assert torch.equal(out, _lookup(blk.corr_pyramid, G(coords), r, W2))                # skew == row layout
+    assert same(out, c_oracle.corr1d_lookup(pyr, coords, r))                  # sampler: bit exact
+    assert same(out, _lookup(blk.corr_pyramid, G(coords), r, W2))             # skew == row layout
 
 
 @settings(**SET)
@@ -100,4 +108,4 @@ def test_pcv_random(c_oracle, B, C, H, W, L, S, Gn, ds, seed):
     own = c_oracle.pcv_pyramid(pyr[0], L, f)
     for i in range(1, L):
         assert np.array_equal(pyr[i], own[i])
-    assert np.array_equal(blk(G(coords), G(sigma)).cpu().numpy(), c_oracle.pcv_lookup(pyr, coords, sigma, S, f))
+    assert same(blk(G(coords), G(sigma)), c_oracle.pcv_lookup(pyr, coords, sigma, S, f))
