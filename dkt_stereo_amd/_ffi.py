@@ -46,6 +46,9 @@ SIGNATURES = {
     "dkt_conv2d_pack_weights": [_vp, _ip, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_f16s": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_conv2d_stem7_packed_elems": [_i],
+    "dkt_conv2d_stem7_pack": [_vp, _i, _i, _f, _vp, _vp, _i, _vp],
+    "dkt_conv2d_stem7": [_vp, _l, _vp, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_f16s_strided": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
                                 _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_f16s_gate_zr": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
@@ -60,7 +63,7 @@ SIGNATURES = {
     "dkt_interp_bilinear": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
 }
 #: entry points that do not return an int status
-RESTYPES = {"dkt_conv2d_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
+RESTYPES = {"dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
 
 _lib = None
 

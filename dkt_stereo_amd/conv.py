@@ -94,6 +94,7 @@ def clear_weight_cache(module):
     for m in module.modules():
         m.__dict__.pop("_dkt_packed", None)
         m.__dict__.pop("_dkt_folded", None)
+        m.__dict__.pop("_dkt_stem7", None)
         if hasattr(m, "_zr_key"):
             m._zr_key = None
 
@@ -120,9 +121,9 @@ def hip_eligible(layer):
 
 
 def direct_eligible(layer):
-    """The 7x7 flow/disp stems (Cin <= 4) run on the exact-fp32 direct kernel: 23 us vs 53 us
-    (+ a separate ReLU) on the vendor path.  The kernel also handles 3x3 layers with Cout <= 4
-    (flow/disp head), but at 163 us it loses to the MFMA kernel's 76 us and is not selected."""
+    """The 7x7 stems (Cin <= 4, stride 1) run on dkt_conv2d_stem7 (matrix cores, K laid out over the
+    taps).  The exact-fp32 direct kernel (dkt_conv2d_direct, 26 us for 2->64 @184x312) stays available
+    as _conv2d_direct."""
     if _BACKEND not in _PASSES:
         return False
     cout, cin, kh, kw = layer.weight.shape
@@ -149,6 +150,43 @@ def _conv2d_direct(x, layer, relu, out):
                                       out.data_ptr(), out.stride(0), B, cin, cout, H, W, kh, kw, int(bool(relu)),
                                       _ffi.device_of(x), _ffi.stream_of(x))
     _ffi.check(rc, "dkt_conv2d_direct")
+    return out
+
+
+def _conv2d_stem7(x, layer, relu, out):
+    """7x7 stem (Cin <= 4) on the matrix cores (dkt_conv2d_stem7); packed weights cached on the layer."""
+    _ffi.require_gpu(x)
+    _ffi.require_no_grad(x)
+    if not _dense(x):
+        x = x.contiguous()
+    B, cin, H, W = x.shape
+    w, b = layer.weight, layer.bias
+    cout = w.shape[0]
+    key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+    pk = layer.__dict__.get("_dkt_stem7")
+    L = _ffi.lib()
+    if pk is None or pk.key != key:
+        wmax = float(w.detach().abs().max())
+        scale = 2.0 ** (12 - math.floor(math.log2(wmax)) if wmax > 0 else 0)
+        pk = _Packed()
+        n = L.dkt_conv2d_stem7_packed_elems(cout)
+        pk.hi = torch.empty(n, device=w.device, dtype=torch.float16)
+        pk.lo = torch.empty(n, device=w.device, dtype=torch.float16)
+        wc = w.detach().float().contiguous()
+        rc = L.dkt_conv2d_stem7_pack(wc.data_ptr(), cout, cin, scale, pk.hi.data_ptr(), pk.lo.data_ptr(),
+                                     _ffi.device_of(w), _ffi.stream_of(w))
+        _ffi.check(rc, "dkt_conv2d_stem7_pack")
+        pk.inv_scale = 1.0 / scale
+        pk.bias = None if b is None else b.detach().float().contiguous()
+        pk.key = key
+        layer.__dict__["_dkt_stem7"] = pk
+    if out is None:
+        out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    rc = L.dkt_conv2d_stem7(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
+                            None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale,
+                            out.data_ptr(), out.stride(0), B, cin, cout, H, W, int(bool(relu)),
+                            _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_conv2d_stem7")
     return out
 
 
@@ -185,7 +223,7 @@ def conv2d(x, layer, relu=False, out=None):
     if isinstance(x, (list, tuple)) and len(x) == 1:
         x = x[0]
     if direct_eligible(layer) and not isinstance(x, (list, tuple)):
-        return _conv2d_direct(x, layer, relu, out)
+        return _conv2d_stem7(x, layer, relu, out)
     if not hip_eligible(layer):
         y = _vendor(x, layer, relu)
         if out is not None:

@@ -267,6 +267,18 @@ int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_channels, c
                              const float *h, long h_bstride, float *hout, long hout_bstride,
                              int B, int H, int W, int Ch, int KH, int KW, int passes, int device, void *stream);
 
+/* The 7x7 stems (Cin <= 4, stride 1, padding 3: core/update.py:75, igev_stereo/update.py:81,
+ * core/extractor.py:136) on the fp16 matrix cores with split operands (stem7.hip): K laid out
+ * over (dy, dx, ci) instead of 32-channel chunks.  Weights are pre-packed once per layer
+ * (dkt_conv2d_stem7_pack, `scale` a power of two as for dkt_conv2d_pack_weights);
+ * out = conv * out_scale + bias [ReLU].  Same fp32-class accuracy as dkt_conv2d_f16s(passes=3). */
+long dkt_conv2d_stem7_packed_elems(int Cout);
+int dkt_conv2d_stem7_pack(const float *w, int Cout, int Cin, float scale, void *w_hi, void *w_lo,
+                          int device, void *stream);
+int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
+                     const float *bias, float out_scale, float *y, long y_bstride,
+                     int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream);
+
 /* Direct exact-fp32 convolution (stride 1, "same" padding) for the two extreme shapes of the
  * update block: 3x3 with Cout <= 4 (flow_head.conv2 / disp_head.conv2, core/update.py:10) and
  * 7x7 with Cin <= 4 (convf1 / convd1, core/update.py:75).  w: (Cout,Cin,K,K); optional ReLU. */

@@ -95,6 +95,31 @@ def test_direct_conv_vs_fp64(shape):
     assert float((got.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [("flow", 1, 2, 64, 20, 45), ("disp", 2, 1, 64, 11, 34), ("rgb", 1, 3, 64, 37, 70),
+                                   ("c4_co100", 1, 4, 100, 5, 33), ("tiny", 1, 2, 64, 1, 1)], ids=lambda s: s[0])
+@torch.no_grad()
+def test_stem7_vs_fp64(shape):
+    """dkt_conv2d_stem7 (7x7, Cin <= 4, split-fp16 MFMA with K over the taps) vs an fp64 convolution and
+    the exact-fp32 direct kernel."""
+    from dkt_stereo_amd import conv
+    name, B, cin, cout, H, W = shape
+    conv.set_backend("f16x3")
+    torch.manual_seed(4321)
+    layer = torch.nn.Conv2d(cin, cout, 7, padding=3).to(DEV)
+    assert conv.direct_eligible(layer)
+    x = G(_synth.normal((B, cin, H, W), 97, name, scale=3.0))
+    for relu in (False, True):
+        ref = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=3)
+        ref = ref.clamp_min(0) if relu else ref
+        got = conv.conv2d(x, layer, relu=relu)
+        tol = 3e-6 * max(1.0, float(ref.abs().max()))
+        assert got.shape == ref.shape and float((got.double() - ref).abs().max()) <= tol
+        assert float((got - conv._conv2d_direct(x, layer, relu, None)).abs().max()) <= 2 * tol
+    layer.weight.mul_(2.0)                                   # cache invalidation through the version counter
+    ref2 = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=3)
+    assert float((conv.conv2d(x, layer).double() - ref2).abs().max()) <= 6e-6 * max(1.0, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize("shape", [("s2_k3", 2, 64, 96, 23, 70, 3), ("s2_k3_odd", 1, 96, 128, 9, 33, 3),
                                    ("s2_k1", 2, 64, 96, 12, 41, 1), ("s2_k3_wide", 1, 32, 160, 8, 64, 3),
                                    ("s2_k3_tiny", 1, 8, 24, 1, 1, 3), ("s2_k1_big", 1, 128, 128, 46, 78, 1)],
