@@ -46,6 +46,8 @@ SIGNATURES = {
     "dkt_conv2d_pack_weights": [_vp, _ip, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_f16s": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_instance_norm_stats": [_vp, _vp, _i, _l, _i, _vp],
+    "dkt_instance_norm_add_relu": [_vp, _vp, _vp, _vp, _i, _l, _f, _i, _vp],
     "dkt_conv2d_stem7_packed_elems": [_i],
     "dkt_conv2d_stem7_pack": [_vp, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_stem7": [_vp, _l, _vp, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -91,23 +91,82 @@ extern "C" long dkt_instance_norm_workspace(int planes, long HW) {
     return (long)planes * IN_SPLIT_MAX * 2 * (long)sizeof(double);
 }
 
-extern "C" int dkt_instance_norm(const float *x, float *y, void *workspace, int planes, long HW,
-                                 float eps, int relu, int device, void *stream) {
-    if (!x || !y || !workspace) return DKT_E_NULL;
-    if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;
-    DKT_ENTER(device);
-    hipStream_t st = (hipStream_t)stream;
+static int instnorm_split(int planes, long HW) {
     int S = (2048 + planes - 1) / planes;          // ~2048 blocks in flight
     const long max_split = (HW + 4095) / 4096;      // at least 4096 elements per block
     if (S > max_split) S = (int)max_split;
     if (S > IN_SPLIT_MAX) S = IN_SPLIT_MAX;
     if (S < 1) S = 1;
-    hipLaunchKernelGGL(instnorm_stats_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, st,
+    return S;
+}
+
+extern "C" int dkt_instance_norm_stats(const float *x, void *workspace, int planes, long HW, int device, void *stream) {
+    if (!x || !workspace) return DKT_E_NULL;
+    if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const int S = instnorm_split(planes, HW);
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, (hipStream_t)stream,
                        x, (double *)workspace, HW, S);
-    int rc = dkt_launch_status();
+    return dkt_launch_status();
+}
+
+extern "C" int dkt_instance_norm(const float *x, float *y, void *workspace, int planes, long HW,
+                                 float eps, int relu, int device, void *stream) {
+    if (!x || !y || !workspace) return DKT_E_NULL;
+    if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;
+    int rc = dkt_instance_norm_stats(x, workspace, planes, HW, device, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(instnorm_apply_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, st,
+    DKT_ENTER(device);
+    const int S = instnorm_split(planes, HW);
+    hipLaunchKernelGGL(instnorm_apply_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, (hipStream_t)stream,
                        x, y, (const double *)workspace, HW, S, eps, relu ? 1 : 0, S);
+    return dkt_launch_status();
+}
+
+// The tail of a residual block with instance norm (core/extractor.py:52-60) in one pass:
+//   y = relu(a + relu((c - mean_c) * invstd_c)),  statistics of c from dkt_instance_norm_stats.
+// Replaces the normalise(+ReLU) pass over c and the separate add+ReLU pass.
+__global__ __launch_bounds__(256) void instnorm_add_relu_kernel(const float *__restrict__ a, const float *__restrict__ c,
+                                                                float *__restrict__ y, const double *__restrict__ part,
+                                                                long HW, int S, float eps, int blocks_per_plane) {
+    const int plane = blockIdx.y;
+    double sum = 0.0, sq = 0.0;
+    for (int s = 0; s < S; ++s) {
+        sum += part[((long)plane * S + s) * 2];
+        sq += part[((long)plane * S + s) * 2 + 1];
+    }
+    const double mean_d = sum / (double)HW;
+    double var_d = sq / (double)HW - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d;
+    const float invstd = 1.0f / sqrtf((float)var_d + eps);
+    const float *pa = a + (long)plane * HW, *pc = c + (long)plane * HW;
+    float *q = y + (long)plane * HW;
+    const long stride = (long)blocks_per_plane * 1024;
+    if ((((uintptr_t)pa | (uintptr_t)pc | (uintptr_t)q) & 15) == 0 && (HW & 3) == 0) {
+        for (long i = blockIdx.x * 1024L + 4L * threadIdx.x; i + 3 < HW; i += stride) {
+            const float4 u = *(const float4 *)(pa + i);
+            float4 v = *(const float4 *)(pc + i);
+            v.x = fmaxf(u.x + fmaxf((v.x - mean) * invstd, 0.0f), 0.0f);
+            v.y = fmaxf(u.y + fmaxf((v.y - mean) * invstd, 0.0f), 0.0f);
+            v.z = fmaxf(u.z + fmaxf((v.z - mean) * invstd, 0.0f), 0.0f);
+            v.w = fmaxf(u.w + fmaxf((v.w - mean) * invstd, 0.0f), 0.0f);
+            *(float4 *)(q + i) = v;
+        }
+    } else {
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)blocks_per_plane * 256)
+            q[i] = fmaxf(pa[i] + fmaxf((pc[i] - mean) * invstd, 0.0f), 0.0f);
+    }
+}
+
+extern "C" int dkt_instance_norm_add_relu(const float *a, const float *c, float *y, const void *workspace,
+                                          int planes, long HW, float eps, int device, void *stream) {
+    if (!a || !c || !y || !workspace) return DKT_E_NULL;
+    if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const int S = instnorm_split(planes, HW);
+    hipLaunchKernelGGL(instnorm_add_relu_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, (hipStream_t)stream,
+                       a, c, y, (const double *)workspace, HW, S, eps, S);
     return dkt_launch_status();
 }
 

@@ -82,6 +82,31 @@ def conv_norm_act(conv, norm, x, relu):
     return norm_act(norm, conv(x), relu)
 
 
+def _plain_instance_norm(norm):
+    return isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats
+
+
+def norm_add_relu(norm, x, c):
+    """relu(x + relu(norm(c))): the tail of a residual block.  With an affine-free instance norm
+    (fnet) the normalisation of c is folded into the join (dkt_instance_norm_stats +
+    dkt_instance_norm_add_relu: one pass over c for the statistics, one fused pass), otherwise
+    norm_act + add_relu."""
+    if _plain_instance_norm(norm) and _hip_ok(x) and _hip_ok(c) and x.shape == c.shape:
+        x = x.contiguous()
+        c = c.contiguous()
+        n, ch, h, w = c.shape
+        L = _ffi.lib()
+        ws = torch.empty(L.dkt_instance_norm_workspace(n * ch, h * w), device=c.device, dtype=torch.uint8)
+        y = torch.empty_like(c)
+        rc = L.dkt_instance_norm_stats(c.data_ptr(), ws.data_ptr(), n * ch, h * w, _ffi.device_of(c), _ffi.stream_of(c))
+        _ffi.check(rc, "dkt_instance_norm_stats")
+        rc = L.dkt_instance_norm_add_relu(x.data_ptr(), c.data_ptr(), y.data_ptr(), ws.data_ptr(), n * ch, h * w,
+                                          float(norm.eps), _ffi.device_of(c), _ffi.stream_of(c))
+        _ffi.check(rc, "dkt_instance_norm_add_relu")
+        return y
+    return add_relu(x, norm_act(norm, c, True))
+
+
 def add_relu(a, b):
     """relu(a + b), one pass (dkt_add_relu)."""
     if _hip_ok(a) and _hip_ok(b) and a.shape == b.shape and a.is_contiguous() and b.is_contiguous():
@@ -132,9 +157,11 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         y = conv_norm_act(self.conv1, self.norm1, x, True)
-        y = conv_norm_act(self.conv2, self.norm2, y, True)
         if self.downsample is not None:
             x = conv_norm_act(self.downsample[0], self.norm3, x, False)
+        if _plain_instance_norm(self.norm2):
+            return norm_add_relu(self.norm2, x, self.conv2(y))      # norm2 + ReLU folded into the join
+        y = conv_norm_act(self.conv2, self.norm2, y, True)
         return add_relu(x, y)
 
 

@@ -302,6 +302,13 @@ int dkt_interp_bilinear(const float *x, float *y, long planes, int H, int W, int
 long dkt_instance_norm_workspace(int planes, long HW);
 int dkt_instance_norm(const float *x, float *y, void *workspace, int planes, long HW,
                       float eps, int relu, int device, void *stream);
+/* dkt_instance_norm split in two, and the residual-block tail fused (core/extractor.py:52-60):
+ * y = relu(a + relu(instance_norm(c))) with the statistics of c from dkt_instance_norm_stats
+ * (same workspace, same planes / HW). */
+int dkt_instance_norm_stats(const float *x, void *workspace, int planes, long HW, int device, void *stream);
+int dkt_instance_norm_add_relu(const float *a, const float *c, float *y, const void *workspace,
+                               int planes, long HW, float eps, int device, void *stream);
+
 int dkt_add_relu(const float *a, const float *b, float *y, long n, int device, void *stream);
 
 #ifdef __cplusplus

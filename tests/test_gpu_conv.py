@@ -256,7 +256,13 @@ def test_streaming_helpers_vs_torch():
         assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-6
         odd = torch.empty(B, C, 2 * H + 1, 2 * W - 1, device=DEV)
         assert float((interp(x, odd) - F.interpolate(x, odd.shape[2:], mode="bilinear", align_corners=True)).abs().max()) <= 2e-6
+    from dkt_stereo_amd.extractor import norm_add_relu
     inorm = torch.nn.InstanceNorm2d(8)
+    for (B, C, H, W) in ((2, 8, 33, 47), (1, 8, 64, 128), (1, 8, 3, 5)):
+        xa = G(_synth.normal((B, C, H, W), 94, "ja%d" % H))
+        xc = G(_synth.normal((B, C, H, W), 94, "jc%d" % H, scale=3.0)) + 0.7
+        want = torch.relu(xa.double() + torch.relu(inorm(xc.double()))).float()
+        assert float((norm_add_relu(inorm, xa, xc) - want).abs().max()) <= 3e-6
     for (B, C, H, W) in ((2, 8, 33, 47), (1, 8, 64, 128), (1, 8, 3, 5)):
         x = G(_synth.normal((B, C, H, W), 93, "in%d" % H, scale=3.0)) + 1.5
         for relu in (False, True):

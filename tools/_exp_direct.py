@@ -19,5 +19,5 @@ with torch.no_grad():
         err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
         t_d = timeit(lambda: conv._conv2d_direct(x, layer, False, None))
         conv.set_backend("miopen"); t_m = timeit(lambda: conv.conv2d(x, layer)); conv.set_backend("f16x3")
-        t_f = timeit(lambda: conv.conv2d([x], layer)) if k == 3 else float("nan")   # list -> MFMA path... (single-element list is unwrapped)
+        t_f = timeit(lambda: conv.conv2d([x], layer))   # default path (single-element list is unwrapped)
         print("%d->%d k%d %dx%d B=%d  direct %.1f us  miopen %.1f us  conv2d(default) %.1f us  rel err %.1e" % (cin, cout, k, H, W, B, t_d, t_m, t_f, err), flush=True)
