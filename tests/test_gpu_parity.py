@@ -358,6 +358,35 @@ def test_igev_loop(golden):
     assert maxabs(mask, g["small/mask"]) <= 1e-3
 
 
+@torch.no_grad()
+def test_igev_iterate_graph_pipeline_equals_plain_loop(golden):
+    """dkt_stereo_amd.igev_loop.igev_iterate (HIP graph + GRUs pipelined across iterations on two
+    streams) is bit-identical to the reference-order loop and matches the reference fixture."""
+    from dkt_stereo_amd.geometry import Combined_Geo_Encoding_Volume
+    from dkt_stereo_amd.igev_loop import _plain, igev_iterate
+    c = _cases.IGEV_LOOP_CASES["small"]
+    s = c["seed"]
+    blk, _ = _make_block(dict(seed=s, igev=True, n=3))
+    m1, m2, geo, disp, coords = _cases.geo_inputs(dict(c, L=2, r=4))
+    B, H, W = c["B"], c["H"], c["W"]
+    net = [G(np.tanh(_synth.normal((B, 128, H >> i, W >> i), s, "net%d" % i))) for i in range(3)]
+    inp = [list(G(_synth.normal((B, 384, H >> i, W >> i), s, "inp%d" % i, scale=0.5)).split(128, dim=1)) for i in range(3)]
+    geo_fn = Combined_Geo_Encoding_Volume(G(m1), G(m2), G(geo), radius=4, num_levels=2)
+    d0 = G(np.abs(disp))
+    g = golden("igev_loop")
+    want_d, want_m, want_net = _plain(blk, geo_fn, d0, G(coords), [t.clone() for t in net], inp, c["iters"])
+    assert maxabs(want_d, g["small/disp"]) <= 1e-3 and maxabs(want_m, g["small/mask"]) <= 1e-3
+    cache = {}
+    for _ in range(2):                               # second call replays the cached graph
+        got_d, got_m, got_net = igev_iterate(blk, geo_fn, d0, G(coords), [t.clone() for t in net], inp, c["iters"], cache=cache)
+        assert torch.equal(got_d, want_d) and torch.equal(got_m, want_m)
+        assert torch.equal(got_net[0], want_net[0]) and torch.equal(got_net[1], want_net[1])
+    # more iterations than the fixture has: still identical to the plain loop
+    w7 = _plain(blk, geo_fn, d0, G(coords), [t.clone() for t in net], inp, 7)
+    g7 = igev_iterate(blk, geo_fn, d0, G(coords), [t.clone() for t in net], inp, 7, cache=cache)
+    assert torch.equal(g7[0], w7[0]) and torch.equal(g7[1], w7[1])
+
+
 # ---------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties (no oracle at this size)
 # ---------------------------------------------------------------------------------
