@@ -14,6 +14,8 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--pair", type=int, default=-3, help="index of the corr1d_build dispatch that opens the window")
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--timeline", type=int, default=None, metavar="IT",
+                    help="also list every dispatch of GRU iteration IT of the pair (start offset, duration, grid)")
     ap.add_argument("--phases", action="store_true", help="split the pair into the GRU loop (corr build .. last "
                     "iteration) and the rest (upsampling + the next pair's encoders)")
     a = ap.parse_args()
@@ -22,6 +24,16 @@ def main():
     idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
     lo, hi = idx[a.pair], idx[a.pair + 1]
     win = rows[lo:hi]
+    if a.timeline is not None:
+        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"]]
+        it = win[lk[a.timeline]:lk[a.timeline + 1]]
+        t0 = int(it[0]["Start_Timestamp"])
+        print("# dispatches of GRU iteration %d (start offset us, duration us, kernel, grid threads); two streams overlap" % a.timeline)
+        for r in it:
+            n = re.sub(r"^void ", "", re.sub(r"\(.*", "", r["Kernel_Name"]))[:64]
+            print("%9.1f %9.1f  %-64s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
+                                             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, n, r.get("Grid_Size_X", r.get("Grid_Size", ""))))
+        print("# iteration wall: %.1f us" % ((int(it[-1]["End_Timestamp"]) - t0) / 1e3))
     if a.phases:
         lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"]]
         end = lk[-1] + (lk[-1] - lk[-2])          # the last iteration is as long as the one before it
