@@ -12,9 +12,11 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libdktstereo.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-ffp-contract=off",  # the sampler arithmetic is reproduced bit for bit
-         "-Wno-pass-failed"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+          "-ffp-contract=off",  # the sampler arithmetic is reproduced bit for bit
+          "-Wno-pass-failed"]
+FLAGS = CFLAGS + ["-shared"]       # single-command form: hipcc FLAGS csrc/*.hip -o libdktstereo.so
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 
 def sources():
@@ -33,14 +35,40 @@ def _stale():
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    # one object per source, compiled in parallel; conv2d.hip (the long pole: dozens of kernel
+    # instantiations) is compiled as four translation units selected by -DCONV_TU_PASSES
+    jobs = []
+    for src in sources():
+        stem = os.path.splitext(os.path.basename(src))[0]
+        if stem == "conv2d":
+            for tu in (0, 1, 2, 3):
+                jobs.append((src, os.path.join(OBJ_DIR, "conv2d_tu%d.o" % tu), ["-DCONV_TU_PASSES=%d" % tu]))
+        else:
+            jobs.append((src, os.path.join(OBJ_DIR, stem + ".o"), []))
+
+    def compile_one(job):
+        src, obj, extra = job
+        cmd = [HIPCC] + CFLAGS + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return job, subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(len(jobs), int(os.environ.get("DKT_BUILD_JOBS", os.cpu_count() or 4))))
+    with ThreadPoolExecutor(workers) as pool:
+        results = list(pool.map(compile_one, jobs))
+    for (src, obj, extra), res in results:
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout)
+            raise RuntimeError("hipcc failed compiling %s %s" % (os.path.basename(src), " ".join(extra)))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for (_, obj, _), _ in results] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout)
-        raise RuntimeError("hipcc failed building libdktstereo.so")
+        raise RuntimeError("hipcc failed linking libdktstereo.so")
     return LIB
 
 

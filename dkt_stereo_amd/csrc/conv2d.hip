@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
 // with the input-channel axis re-chunked to match the per-source 32-channel
 // padding of the activation operands.  One thread per packed element.
 // ---------------------------------------------------------------------------
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 0
 struct PackArgs {
     const float *w;
     _Float16 *whi, *wlo;
@@ -515,6 +516,8 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(PackArgs a) {
 }
 
 // output channels are owned 64 per wave; the packed image is padded to that granule
+#endif  // CONV_TU_PASSES == 0
+
 static int conv_cout_pad(int Cout) { return (Cout + 63) & ~63; }
 
 static int conv_padded_channels(const int *src_ch, int nsrc) {
@@ -523,6 +526,7 @@ static int conv_padded_channels(const int *src_ch, int nsrc) {
     return t;
 }
 
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 0
 extern "C" long dkt_conv2d_packed_elems(const int *src_channels, int nsrc, int Cout, int KH, int KW) {
     if (!src_channels || nsrc < 1 || nsrc > CONV_MAX_SRC || Cout <= 0 || KH <= 0 || KW <= 0) return DKT_E_SHAPE;
     return (long)KH * KW * (conv_padded_channels(src_channels, nsrc) / 16) * conv_cout_pad(Cout) * 16;
@@ -555,6 +559,8 @@ extern "C" int dkt_conv2d_pack_weights(const float *w, const int *src_channels, 
                        (hipStream_t)stream, a);
     return dkt_launch_status();
 }
+
+#endif  // CONV_TU_PASSES == 0 (weight packer)
 
 // Resident blocks the device holds of one instantiation (occupancy x CUs), cached per device.
 static int conv_slots(const void *kern, size_t lds, int dev, int threads) {
@@ -658,6 +664,33 @@ static int launch_conv_stride2(const ConvArgs &a, int B, hipStream_t st) {
     return launch_conv<KS, 4, 1, 1, PASSES, CONV_ABL, 2, 2>(a, B, st);                      // 256 co x 1 row
 }
 
+// The kernel instantiations are split by number of MFMA passes so that the build can compile them as
+// three parallel translation units (dkt_stereo_amd/build.py: -DCONV_TU_PASSES=1|2|3; =0 holds the ABI
+// and the weight packer).  Compiled without the macro this file is one complete translation unit.
+int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st);
+int conv2d_launch_p2(const ConvArgs &a, int B, int KH, int stride, hipStream_t st);
+int conv2d_launch_p3(const ConvArgs &a, int B, int KH, int stride, hipStream_t st);
+
+template <int PASSES>
+static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) {
+    if (stride == 2) {
+        if (KH == 3) return launch_conv_stride2<3, PASSES>(a, B, st);
+        return launch_conv_stride2<1, PASSES>(a, B, st);
+    }
+    if (KH == 3) return launch_conv_shape<3, PASSES>(a, B, st);
+    return launch_conv_shape<1, PASSES>(a, B, st);
+}
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 1
+int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) { return conv2d_launch_passes<1>(a, B, KH, stride, st); }
+#endif
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 2
+int conv2d_launch_p2(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) { return conv2d_launch_passes<2>(a, B, KH, stride, st); }
+#endif
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 3
+int conv2d_launch_p3(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) { return conv2d_launch_passes<3>(a, B, KH, stride, st); }
+#endif
+
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 0
 struct ConvEpilogue {
     int kind;
     const float *c0, *c1, *h;
@@ -711,24 +744,9 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
     }
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 2) {
-        if (KH == 3) {
-            if (passes == 3) return launch_conv_stride2<3, 3>(a, B, st);
-            if (passes == 2) return launch_conv_stride2<3, 2>(a, B, st);
-            return launch_conv_stride2<3, 1>(a, B, st);
-        }
-        if (passes == 3) return launch_conv_stride2<1, 3>(a, B, st);
-        if (passes == 2) return launch_conv_stride2<1, 2>(a, B, st);
-        return launch_conv_stride2<1, 1>(a, B, st);
-    }
-    if (KH == 3) {
-        if (passes == 3) return launch_conv_shape<3, 3>(a, B, st);
-        if (passes == 2) return launch_conv_shape<3, 2>(a, B, st);
-        return launch_conv_shape<3, 1>(a, B, st);
-    }
-    if (passes == 3) return launch_conv_shape<1, 3>(a, B, st);
-    if (passes == 2) return launch_conv_shape<1, 2>(a, B, st);
-    return launch_conv_shape<1, 1>(a, B, st);
+    if (passes == 3) return conv2d_launch_p3(a, B, KH, stride, st);
+    if (passes == 2) return conv2d_launch_p2(a, B, KH, stride, st);
+    return conv2d_launch_p1(a, B, KH, stride, st);
 }
 
 extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride,
@@ -776,3 +794,4 @@ extern "C" int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_
     return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, hout, hout_bstride,
                             B, H, W, Ch, KH, KW, 0, passes, &e, device, stream);
 }
+#endif  // CONV_TU_PASSES == 0 (ABI entry points)
