@@ -1,11 +1,12 @@
-"""Feature / context encoders for the end-to-end harness.
+"""Feature / context encoders: the callers' side of the hot path.
 
-Out of scope for the HIP work (they run once per pair and are plain dense 2-D
-convolutions -> MIOpen), but the harness needs them to
-produce the feature maps and GRU context the hot path consumes, and published
-checkpoints must load: parameter names follow the reference's
+They run once per pair and produce the feature maps and GRU context the hot path consumes;
+published checkpoints must load, so parameter names follow the reference's
 ``core/extractor.py`` (``BasicEncoder`` :122-197, ``MultiBasicEncoder`` :199-300,
-``ResidualBlock`` :6-60).
+``ResidualBlock`` :6-60).  On a HIP device in inference every convolution runs on this
+library's kernels (1x1 / 3x3 with stride 1 or 2: dkt_conv2d_f16s[_strided]; the 7x7 stem:
+dkt_conv2d_stem7), eval-mode BatchNorm is folded into the convolution, instance norm and the
+residual join are streaming kernels; anything else (training, CPU, group norm) is plain torch.
 """
 import torch
 import torch.nn as nn
@@ -119,9 +120,9 @@ def add_relu(a, b):
 
 
 class _Conv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters, same state-dict keys) whose stride-1 1x1 / 3x3 inference
-    calls go through dkt_stereo_amd.conv.conv2d, i.e. the split-fp16 MFMA kernel that the
-    update block uses; everything else (stride 2, 7x7 stem, autograd, CPU) is plain torch."""
+    """nn.Conv2d (same parameters, same state-dict keys) whose inference calls with stride 1 or 2
+    go through dkt_stereo_amd.conv.conv2d (split-fp16 MFMA kernels; conv2d itself falls back to
+    the vendor convolution for shapes it does not cover); autograd and CPU are plain torch."""
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.float32 and self.stride in ((1, 1), (2, 2)) and self.dilation == (1, 1)
