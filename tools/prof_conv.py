@@ -30,6 +30,12 @@ with torch.no_grad():
         cz, cr = (torch.randn(1, 128, 184, 312, device=dev) for _ in range(2))
         for _ in range(reps):
             conv.conv2d_gate_zr(xs, layer, cz, cr, xs[0])
+    elif which == "small":        # a latency-bound small layer: motion encoder convc2, 64->64 3x3 at 184x312
+        conv.set_backend("f16x3")
+        layer = torch.nn.Conv2d(64, 64, 3, padding=1).to(dev)
+        x = torch.randn(1, 64, 184, 312, device=dev)
+        for _ in range(reps):
+            conv.conv2d(x, layer, relu=True)
     elif which == "enc":          # narrow encoder layer: 64->64 3x3 at 368x624
         conv.set_backend("f16x3")
         layer = torch.nn.Conv2d(64, 64, 3, padding=1).to(dev)
