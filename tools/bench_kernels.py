@@ -87,7 +87,7 @@ def bench_build():
     f1, f2 = (torch.randn(B, C, H, W, device=DEV) for _ in range(2))
     fl = 2.0 * B * H * W * W * C
     by = 2 * B * C * H * W * 4 + B * H * W * 4 * sum(W >> i for i in range(4))
-    report("corr1d_build cfg2", timeit(lambda: CorrBlock1D(f1, f2, num_levels=4, radius=4), n=20), bytes_=by, flops=fl)
+    report("corr1d_build + corr1d_skew cfg2 (CorrBlock1D ctor)", timeit(lambda: CorrBlock1D(f1, f2, num_levels=4, radius=4), n=20), bytes_=by, flops=fl)
     report("torch einsum+pools (rocBLAS) cfg2",
            timeit(lambda: _torch_build(f1, f2), n=10), flops=fl)
 
