@@ -165,6 +165,7 @@ E2E_CASES = {
     "64x128_it12":  dict(seed=1, B=1, H=64, W=128, iters=12, shift=12, stride=1),
     "256x512_it8":  dict(seed=0, B=1, H=256, W=512, iters=8, shift=12, stride=4),   # BASELINE cfg 1
     "256x512_it32": dict(seed=2, B=1, H=256, W=512, iters=32, shift=40, stride=4),
+    "736x1248_it32": dict(seed=3, B=1, H=736, W=1248, iters=32, shift=40, stride=8),  # BASELINE cfg 2: the benchmark workload
 }
 E2E_WEIGHT_SEED = 7
 
