@@ -300,6 +300,26 @@ def main():
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
                             "launches_timed": len(look_ms)},
     }
+    # EPE against the reference itself (BASELINE.json's "EPE vs ref"): tests/golden/raft_e2e.npz holds the
+    # reference's CPU output for this exact workload (seed 3, shift 40, 32 iterations, every 8th pixel)
+    if default_shape and args.iters == 32:
+        try:
+            import numpy as np
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _cases
+            c = _cases.E2E_CASES["736x1248_it32"]
+            g = np.load(os.path.join(ROOT, "tests", "golden", "raft_e2e.npz"))
+            r1, r2 = _synth.image_pair(c["seed"], 1, c["H"], c["W"], c["shift"])
+            with torch.no_grad():
+                _, up = model(torch.from_numpy(r1).to(dev), torch.from_numpy(r2).to(dev), iters=32, test_mode=True)
+            st = int(g["736x1248_it32/stride"])
+            diff = np.abs(up[:, :, ::st, ::st].cpu().numpy() - g["736x1248_it32/flow_up"])
+            out["epe_vs_reference"] = float(diff.mean())
+            out["max_abs_vs_reference"] = float(diff.max())
+            out["reference_fixture"] = "tests/golden/raft_e2e.npz:736x1248_it32 (jiaw-z/DKT-Stereo RAFTStereo.forward on CPU, fp32)"
+        except (OSError, KeyError, ImportError) as e:          # fixture absent: report nothing rather than fail
+            out["epe_vs_reference"] = None
+            out["reference_fixture"] = "unavailable: %s" % e
     if not args.skip_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, sd, dict(BASE_CONFIG), i1, i2)
     print(json.dumps(out))
