@@ -127,8 +127,9 @@ class RAFTStereo(nn.Module):
                                                           iter16=(n >= 2), need_mask=need_mask)
         finally:
             self.update_block.inplace_state = False
-        delta_flow[:, 1] = 0.0          # stereo: project onto the epipolar line
-        coords1.add_(delta_flow)
+        # stereo: project onto the epipolar line (raft_stereo.py:165-166: delta_flow[:,1] = 0; coords1 += delta)
+        # -- one launch: only the x plane changes (y + 0.0 is y)
+        coords1[:, :1].add_(delta_flow[:, :1])
         for dst, src in zip(net_state, nets):
             if dst is not src:
                 dst.copy_(src)
@@ -180,8 +181,9 @@ class RAFTStereo(nn.Module):
             ub.encoder.branch_streams = False
             ub.side_stream = saved_side
             ub.inplace_state = False
-        delta_flow[:, 1] = 0.0          # stereo: project onto the epipolar line
-        coords1.add_(delta_flow)
+        # stereo: project onto the epipolar line (raft_stereo.py:165-166: delta_flow[:,1] = 0; coords1 += delta)
+        # -- one launch: only the x plane changes (y + 0.0 is y)
+        coords1[:, :1].add_(delta_flow[:, :1])
         for dst, src in zip(net_state, nets):
             if dst is not src:
                 dst.copy_(src)
