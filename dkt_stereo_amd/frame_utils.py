@@ -1,149 +1,146 @@
-"""On-disk readers / writers either side of the inference path: the formats
-``core/utils/frame_utils.py`` handles for the stereo datasets the reference evaluates on
-(``evaluate_stereo.py:83-330``).  Host-side numpy; same function names, argument meaning and
-return conventions (``(disp, valid)`` pairs) as the reference.  PIL replaces the reference's
-cv2 / imageio calls (neither is needed for these formats).  Not provided: the 48-bit KITTI
-*optical-flow* PNGs (readFlowKITTI / writeFlowKITTI need a 16-bit RGB decoder; they are not on
-the stereo path).
+"""On-disk readers / writers either side of the inference path: the dataset formats
+``core/utils/frame_utils.py`` handles for the stereo benchmarks the reference evaluates on
+(``evaluate_stereo.py:83-330``).  Host-side numpy + PIL (the reference's cv2 / imageio calls are not
+needed for these formats); function names, argument meaning and return conventions -- arrays, or
+``(disparity, valid)`` pairs -- are the reference's, so dataset code can import this module instead.
+``tests/test_frame_utils.py`` pins every reader on the reference's own output for the same files.
+
+Not provided: the 48-bit KITTI *optical-flow* PNGs (``readFlowKITTI`` / ``writeFlowKITTI`` need a 16-bit
+RGB decoder; they are not on the stereo path).
 """
 import json
-import re
-from os.path import basename, exists, splitext
+import os
+import struct
 
 import numpy as np
 from PIL import Image
 
-TAG_CHAR = np.array([202021.25], np.float32)
+FLO_MAGIC = 202021.25                     # Middlebury .flo tag ("PIEH" read as a little-endian float)
+TAG_CHAR = np.array([FLO_MAGIC], np.float32)
 
 
+# ----------------------------------------------------------------------------- Middlebury .flo
 def readFlow(fn):
-    """Middlebury .flo (frame_utils.py:41-60): little-endian, magic 202021.25, then w, h, (h,w,2) fp32."""
-    with open(fn, 'rb') as f:
-        magic = np.fromfile(f, np.float32, count=1)
-        if magic.size != 1 or 202021.25 != magic[0]:
-            print('Magic number incorrect. Invalid .flo file')
-            return None
-        w = int(np.fromfile(f, np.int32, count=1)[0])
-        h = int(np.fromfile(f, np.int32, count=1)[0])
-        data = np.fromfile(f, np.float32, count=2 * w * h)
-        return np.resize(data, (h, w, 2))
+    """frame_utils.py:41-60.  Layout: float32 magic, int32 width, int32 height, then height x width
+    (u, v) float32 pairs, all little endian.  A wrong magic prints a message and yields None."""
+    raw = open(fn, 'rb').read()
+    if len(raw) < 4 or struct.unpack('<f', raw[:4])[0] != FLO_MAGIC:
+        print('Magic number incorrect. Invalid .flo file')
+        return None
+    width, height = struct.unpack('<ii', raw[4:12])
+    uv = np.frombuffer(raw, dtype='<f4', count=2 * width * height, offset=12)
+    return np.resize(uv, (height, width, 2))
 
 
 def writeFlow(filename, uv, v=None):
-    """frame_utils.py:106-136: u and v interleaved per pixel."""
+    """frame_utils.py:106-136.  ``uv`` is (H, W, 2), or ``uv`` / ``v`` are the two (H, W) planes."""
     if v is None:
         assert uv.ndim == 3 and uv.shape[2] == 2
-        u, v = uv[:, :, 0], uv[:, :, 1]
+        u, v = uv[..., 0], uv[..., 1]
     else:
         u = uv
     assert u.shape == v.shape
     height, width = u.shape
+    interleaved = np.stack([u, v], axis=-1).astype('<f4')
     with open(filename, 'wb') as f:
-        f.write(TAG_CHAR.tobytes())
-        np.array(width).astype(np.int32).tofile(f)
-        np.array(height).astype(np.int32).tofile(f)
-        tmp = np.zeros((height, width * 2))
-        tmp[:, np.arange(width) * 2] = u
-        tmp[:, np.arange(width) * 2 + 1] = v
-        tmp.astype(np.float32).tofile(f)
+        f.write(struct.pack('<fii', FLO_MAGIC, width, height))
+        f.write(interleaved.tobytes())
 
 
+# ----------------------------------------------------------------------------- PFM
 def readPFM(file):
-    """frame_utils.py:62-92: 'PF' (3 channels) / 'Pf' (1), 'W H', scale (negative = little endian),
-    rows stored bottom-up."""
+    """frame_utils.py:62-92.  Header lines: ``PF`` (3 channels) or ``Pf`` (1), ``<width> <height>``, a scale
+    whose sign gives the byte order (negative = little endian); rows are stored bottom-up."""
     with open(file, 'rb') as f:
-        header = f.readline().rstrip()
-        if header == b'PF':
-            color = True
-        elif header == b'Pf':
-            color = False
-        else:
+        kind = f.readline().rstrip()
+        if kind not in (b'PF', b'Pf'):
             raise Exception('Not a PFM file.')
-        dim_match = re.match(rb'^(\d+)\s(\d+)\s$', f.readline())
-        if not dim_match:
+        dims = f.readline().split()
+        if len(dims) != 2 or not all(d.isdigit() for d in dims):
             raise Exception('Malformed PFM header.')
-        width, height = map(int, dim_match.groups())
-        scale = float(f.readline().rstrip())
-        endian = '<' if scale < 0 else '>'
-        data = np.fromfile(f, endian + 'f')
-    shape = (height, width, 3) if color else (height, width)
-    return np.flipud(np.reshape(data, shape))
+        width, height = int(dims[0]), int(dims[1])
+        little = float(f.readline().rstrip()) < 0
+        samples = np.fromfile(f, '<f' if little else '>f')
+    shape = (height, width, 3) if kind == b'PF' else (height, width)
+    return np.flipud(samples.reshape(shape))
 
 
 def writePFM(file, array):
-    """frame_utils.py:94-104: single-channel, little endian."""
-    assert type(file) is str and type(array) is np.ndarray and splitext(file)[1] == ".pfm"
+    """frame_utils.py:94-104: one channel, little endian (scale line ``-1``)."""
+    assert type(file) is str and type(array) is np.ndarray and os.path.splitext(file)[1] == ".pfm"
+    rows, cols = array.shape
     with open(file, 'wb') as f:
-        H, W = array.shape
-        for header in ("Pf\n", "%d %d\n" % (W, H), "-1\n"):
-            f.write(str.encode(header))
-        f.write(np.flip(array, axis=0).astype(np.float32).tobytes())
+        f.write(("Pf\n%d %d\n-1\n" % (cols, rows)).encode())
+        f.write(np.ascontiguousarray(array[::-1], dtype=np.float32).tobytes())
+
+
+# ----------------------------------------------------------------------------- disparity maps
+def _with_valid(disp):
+    return disp, disp > 0
 
 
 def readDispKITTI(filename):
-    """frame_utils.py:152-155: 16-bit PNG, disparity = value / 256, 0 = invalid."""
-    disp = np.array(Image.open(filename)).astype(np.uint16) / 256.0
-    valid = disp > 0.0
-    return disp, valid
+    """frame_utils.py:152-155: 16-bit grey PNG holding disparity * 256; 0 marks missing ground truth."""
+    return _with_valid(np.asarray(Image.open(filename), dtype=np.uint16) / 256.0)
 
 
 def readDispSintelStereo(file_name):
-    """frame_utils.py:158-164."""
-    a = np.array(Image.open(file_name))
-    d_r, d_g, d_b = np.split(a, axis=2, indices_or_sections=3)
-    disp = (d_r * 4 + d_g / (2 ** 6) + d_b / (2 ** 14))[..., 0]
-    mask = np.array(Image.open(file_name.replace('disparities', 'occlusions')))
-    valid = ((mask == 0) & (disp > 0))
-    return disp, valid
+    """frame_utils.py:158-164: disparity packed into the three 8-bit channels (R*4 + G/2^6 + B/2^14);
+    the occlusion mask lives in the parallel ``occlusions`` directory."""
+    rgb = np.array(Image.open(file_name))
+    r, g, b = (rgb[..., i:i + 1] for i in range(3))
+    disp = (r * 4 + g / (2 ** 6) + b / (2 ** 14))[..., 0]
+    occluded = np.array(Image.open(file_name.replace('disparities', 'occlusions')))
+    return disp, (occluded == 0) & (disp > 0)
 
 
 def readDispFallingThings(file_name):
-    """frame_utils.py:167-174."""
-    a = np.array(Image.open(file_name))
-    with open('/'.join(file_name.split('/')[:-1] + ['_camera_settings.json']), 'r') as f:
-        intrinsics = json.load(f)
-    fx = intrinsics['camera_settings'][0]['intrinsic_settings']['fx']
-    disp = (fx * 6.0 * 100) / a.astype(np.float32)
-    valid = disp > 0
-    return disp, valid
+    """frame_utils.py:167-174: depth PNG in 0.01 cm units, baseline 6 cm, focal length from the sequence's
+    ``_camera_settings.json``."""
+    depth = np.array(Image.open(file_name))
+    with open(os.path.join(os.path.dirname(file_name), '_camera_settings.json')) as f:
+        fx = json.load(f)['camera_settings'][0]['intrinsic_settings']['fx']
+    return _with_valid((fx * 6.0 * 100) / depth.astype(np.float32))
 
 
 def readDispTartanAir(file_name):
-    """frame_utils.py:177-181."""
-    depth = np.load(file_name)
-    disp = 80.0 / depth
-    valid = disp > 0
-    return disp, valid
+    """frame_utils.py:177-181: ``.npy`` depth in metres, disparity = 80 / depth."""
+    return _with_valid(80.0 / np.load(file_name))
 
 
 def readDispMiddlebury(file_name):
-    """frame_utils.py:184-196."""
-    if basename(file_name) == 'disp0GT.pfm':
+    """frame_utils.py:184-196: ``disp0GT.pfm`` comes with a non-occlusion mask PNG (255 = visible);
+    ``disp0.pfm`` marks invalid pixels with inf."""
+    name = os.path.basename(file_name)
+    if name == 'disp0GT.pfm':
         disp = readPFM(file_name).astype(np.float32)
-        assert len(disp.shape) == 2
-        nocc_pix = file_name.replace('disp0GT.pfm', 'mask0nocc.png')
-        assert exists(nocc_pix)
-        nocc_pix = np.array(Image.open(nocc_pix)) == 255
-        assert np.any(nocc_pix)
-        return disp, nocc_pix
-    elif basename(file_name) == 'disp0.pfm':
+        assert disp.ndim == 2
+        mask_file = file_name.replace('disp0GT.pfm', 'mask0nocc.png')
+        assert os.path.exists(mask_file)
+        visible = np.array(Image.open(mask_file)) == 255
+        assert np.any(visible)
+        return disp, visible
+    if name == 'disp0.pfm':
         disp = readPFM(file_name).astype(np.float32)
-        valid = disp < 1e3
-        return disp, valid
+        return disp, disp < 1e3
+
+
+# ----------------------------------------------------------------------------- dispatch by extension
+def _read_pfm_image(path):
+    data = readPFM(path).astype(np.float32)
+    return data if data.ndim == 2 else data[:, :, :-1]
+
+
+_READERS = {
+    '.png': Image.open, '.jpeg': Image.open, '.ppm': Image.open, '.jpg': Image.open,
+    '.bin': np.load, '.raw': np.load, '.npy': np.load,
+    '.flo': lambda p: readFlow(p).astype(np.float32),
+    '.pfm': _read_pfm_image,
+}
 
 
 def read_gen(file_name, pil=False):
-    """frame_utils.py:205-224: dispatch on the extension."""
-    ext = splitext(file_name)[-1]
-    if ext in ('.png', '.jpeg', '.ppm', '.jpg'):
-        return Image.open(file_name)
-    elif ext in ('.bin', '.raw', '.npy'):
-        return np.load(file_name)
-    elif ext == '.flo':
-        return readFlow(file_name).astype(np.float32)
-    elif ext == '.pfm':
-        flow = readPFM(file_name).astype(np.float32)
-        if len(flow.shape) == 2:
-            return flow
-        return flow[:, :, :-1]
-    return []
+    """frame_utils.py:205-224: images as PIL objects, arrays for everything else, ``[]`` for an unknown
+    extension."""
+    reader = _READERS.get(os.path.splitext(file_name)[-1])
+    return reader(file_name) if reader is not None else []
