@@ -26,6 +26,8 @@ SIGNATURES = {
     "dkt_convex_upsample": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_context_upsample": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "dkt_corr1d_lookup_bwd": [_vp, _vp, _l, _pp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_geo_lookup_bwd": [_vp, _vp, _vp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_geo_pool_bwd": [_pp, _vp, _l, _i, _l, _i, _i, _vp],
     "dkt_corr1d_pool_bwd": [_pp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_pool_rows": [_vp, _vp, _l, _i, _i, _i, _vp],
     "dkt_pcv_lookup": [_pp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

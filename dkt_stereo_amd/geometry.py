@@ -9,11 +9,78 @@ Differences a caller cannot observe through ``__call__``: the geometry volume
 is kept in the network's native (B,C,D,H,W) layout (the reference's 88 MB
 ``permute(0,3,4,1,2).reshape`` copy, :18, is not made); pyramid level i is
 (B,C,D>>i,H,W) instead of (B*H*W,C,1,D>>i).
+
+Differentiable w.r.t. ``geo_volume`` and the two feature maps: when they require grad the
+pyramids and every lookup are autograd nodes backed by dkt_geo_lookup_bwd / dkt_geo_pool_bwd /
+dkt_corr1d_pool_bwd; ``disp`` must be detached, as the reference's loop does.
 """
 import torch
 
 from . import _ffi
-from .corr import _build_pyramid
+from .corr import _BuildFn, _build_pyramid
+
+
+def _pool_geo(geo_volume, num_levels):
+    """(B,C,D,H,W) -> list of num_levels levels, level i = pairwise mean along D of level i-1 (geometry.py:23-25)."""
+    b, c, d, h, w = geo_volume.shape
+    pyr = [geo_volume]
+    for _ in range(1, num_levels):
+        src = pyr[-1]
+        di = src.shape[2]
+        dst = torch.empty((b, c, di // 2, h, w), device=src.device, dtype=torch.float32)
+        rc = _ffi.lib().dkt_pool_d(src.data_ptr(), dst.data_ptr(), b * c, di, h * w, _ffi.device_of(src), _ffi.stream_of(src))
+        _ffi.check(rc, "dkt_pool_d")
+        pyr.append(dst)
+    return pyr
+
+
+class _GeoPyramidFn(torch.autograd.Function):
+    """geo_volume -> pyramid levels; backward folds the pooling chain (dkt_geo_pool_bwd)."""
+
+    @staticmethod
+    def forward(ctx, geo_volume, num_levels):
+        ctx.meta = (tuple(geo_volume.shape), num_levels)
+        return tuple(_pool_geo(geo_volume, num_levels))
+
+    @staticmethod
+    def backward(ctx, *glv):
+        (b, c, d, h, w), L = ctx.meta
+        dev = next(g for g in glv if g is not None).device
+        glv = [g.contiguous() if g is not None else torch.zeros((b, c, d >> i, h, w), device=dev)
+               for i, g in enumerate(glv)]
+        out = torch.empty((b, c, d, h, w), device=dev, dtype=torch.float32)
+        rc = _ffi.lib().dkt_geo_pool_bwd(_ffi.ptr_array(glv), out.data_ptr(), b * c, d, h * w, L,
+                                         _ffi.device_of(out), _ffi.stream_of(out))
+        _ffi.check(rc, "dkt_geo_pool_bwd")
+        return out, None
+
+
+class _GeoLookupFn(torch.autograd.Function):
+    """(geometry levels, init-correlation levels) -> lookup; backward scatters into zeroed level-shaped tensors
+    (dkt_geo_lookup_bwd).  disp / coords carry no gradient (the caller detaches disp, igev_stereo.py:200)."""
+
+    @staticmethod
+    def forward(ctx, disp, coords, vol, *levels):
+        L = vol.num_levels
+        ctx.save_for_backward(disp, coords)
+        ctx.vol = vol
+        ctx.shapes = [tuple(t.shape) for t in levels]
+        return vol._lookup(disp, coords, list(levels[:L]), list(levels[L:]))
+
+    @staticmethod
+    def backward(ctx, gout):
+        disp, coords = ctx.saved_tensors
+        vol = ctx.vol
+        L = vol.num_levels
+        b, c, d, h, w = vol._shape
+        gout = gout.contiguous().float()
+        grads = [torch.zeros(s, device=gout.device, dtype=torch.float32) for s in ctx.shapes]
+        rc = _ffi.lib().dkt_geo_lookup_bwd(gout.data_ptr(), disp.data_ptr(), coords.data_ptr(),
+                                           _ffi.ptr_array(grads[:L]), _ffi.ptr_array(grads[L:]),
+                                           b, c, d, h, w, vol._w2, L, vol.radius,
+                                           _ffi.device_of(gout), _ffi.stream_of(gout))
+        _ffi.check(rc, "dkt_geo_lookup_bwd")
+        return (None, None, None) + tuple(grads)
 
 
 class Combined_Geo_Encoding_Volume:
@@ -21,41 +88,50 @@ class Combined_Geo_Encoding_Volume:
         self.num_levels = num_levels
         self.radius = radius
         _ffi.require_gpu(init_fmap1, init_fmap2, geo_volume)
-        _ffi.require_no_grad(init_fmap1, init_fmap2, geo_volume)
         geo_volume = geo_volume.float().contiguous()
         b, c, d, h, w = geo_volume.shape
         self._shape = (b, c, d, h, w)
         self._w2 = init_fmap2.shape[3]
+        grad = torch.is_grad_enabled()
         # all-pairs correlation WITHOUT the 1/sqrt(C) of RAFT (geometry.py:62-69)
-        self.init_corr_pyramid = _build_pyramid(init_fmap1.float(), init_fmap2.float(), num_levels, 1.0)
-        self.geo_volume_pyramid = [geo_volume]
-        for i in range(1, num_levels):
-            src = self.geo_volume_pyramid[-1]
-            di = src.shape[2]
-            dst = torch.empty((b, c, di // 2, h, w), device=src.device, dtype=torch.float32)
-            rc = _ffi.lib().dkt_pool_d(src.data_ptr(), dst.data_ptr(), b * c, di, h * w,
-                                       _ffi.device_of(src), _ffi.stream_of(src))
-            _ffi.check(rc, "dkt_pool_d")
-            self.geo_volume_pyramid.append(dst)
+        if grad and (init_fmap1.requires_grad or init_fmap2.requires_grad):
+            self.init_corr_pyramid = list(_BuildFn.apply(init_fmap1.float(), init_fmap2.float(), num_levels, 1.0))
+        else:
+            self.init_corr_pyramid = _build_pyramid(init_fmap1.float(), init_fmap2.float(), num_levels, 1.0)
+        if grad and geo_volume.requires_grad:
+            self.geo_volume_pyramid = list(_GeoPyramidFn.apply(geo_volume, num_levels))
+        else:
+            self.geo_volume_pyramid = _pool_geo(geo_volume, num_levels)
 
-    def __call__(self, disp, coords):
-        _ffi.require_gpu(disp, coords)
+    def _lookup(self, disp, coords, geo_pyr, init_pyr):
         b, c, d, h, w = self._shape
-        disp = disp.contiguous()
-        coords = coords.contiguous()
         K = 2 * self.radius + 1
         out = torch.empty((b, self.num_levels * K * (c + 1), h, w), device=disp.device, dtype=torch.float32)
-        rc = _ffi.lib().dkt_geo_lookup(_ffi.ptr_array(self.geo_volume_pyramid),
-                                       _ffi.ptr_array(self.init_corr_pyramid),
+        rc = _ffi.lib().dkt_geo_lookup(_ffi.ptr_array(geo_pyr), _ffi.ptr_array(init_pyr),
                                        disp.data_ptr(), coords.data_ptr(), out.data_ptr(),
                                        b, c, d, h, w, self._w2, self.num_levels, self.radius,
                                        _ffi.device_of(disp), _ffi.stream_of(disp))
         _ffi.check(rc, "dkt_geo_lookup")
         return out
 
+    def __call__(self, disp, coords):
+        _ffi.require_gpu(disp, coords)
+        disp = disp.float().contiguous()
+        coords = coords.float().contiguous()
+        levels = self.geo_volume_pyramid + self.init_corr_pyramid
+        if torch.is_grad_enabled() and any(t.requires_grad for t in levels):
+            if disp.requires_grad or coords.requires_grad:
+                raise _ffi.DktError("Combined_Geo_Encoding_Volume: disparity gradients are not implemented; detach "
+                                    "disp as the reference's loop does (igev_stereo.py:200)")
+            return _GeoLookupFn.apply(disp, coords, self, *levels)
+        return self._lookup(disp, coords, self.geo_volume_pyramid, self.init_corr_pyramid)
+
     @staticmethod
     def corr(fmap1, fmap2):
         B, D, H, W1 = fmap1.shape
         W2 = fmap2.shape[3]
-        lvl0, = _build_pyramid(fmap1.float(), fmap2.float(), 1, 1.0)
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            lvl0, = _BuildFn.apply(fmap1.float(), fmap2.float(), 1, 1.0)
+        else:
+            lvl0, = _build_pyramid(fmap1.float(), fmap2.float(), 1, 1.0)
         return lvl0.view(B, H, W1, 1, W2)

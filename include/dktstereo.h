@@ -131,6 +131,16 @@ int dkt_corr1d_lookup_bwd(const float *grad_out, const float *coords_x, long coo
                           float *const *grad_pyr, int B, int H, int W1, int W2, int L, int r,
                           int device, void *stream);
 
+/* IGEV flavour (autograd of meta_arch/igev_stereo/geometry.py:23-58 w.r.t. the volume and the init
+ * correlation; disp is detached upstream, igev_stereo.py:200).  grad_geo[i]: (B,C,D>>i,H,W), grad_init[i]:
+ * (B*H*W, W2>>i), both zeroed (or holding earlier lookups' sums) by the caller. */
+int dkt_geo_lookup_bwd(const float *grad_out, const float *disp, const float *coords,
+                       float *const *grad_geo, float *const *grad_init,
+                       int B, int C, int D, int H, int W, int W2, int L, int r, int device, void *stream);
+/* grad_vol (BC, D, HW) = T_0 with T_{L-1} = g_{L-1}, T_i[d] = g_i[d] + T_{i+1}[d/2]/2 (pairwise-mean pyramid). */
+int dkt_geo_pool_bwd(const float *const *grad_geo, float *grad_vol, long BC, int D, long HW, int L,
+                     int device, void *stream);
+
 /* Folds the avg_pool2d backward chain and the 1/sqrt(C) of CorrBlock1D.corr into the gradient
  * of the un-pooled all-pairs product: grad_vol (B*H*W1, W2) = T_0 / divisor with
  * T_{L-1} = g_{L-1}, T_i[c] = g_i[c] + T_{i+1}[c/2]/2.  The two contractions that follow

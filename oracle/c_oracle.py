@@ -247,3 +247,15 @@ def context_upsample(disp_low, up_weights):
     out = np.empty((B, 4 * h, 4 * w), np.float32)
     lib().orc_context_upsample(_p(disp_low), _p(up_weights), _p(out), B, h, w)
     return out
+
+
+def geo_lookup_bwd(gout, disp, coords, C, D, W2, num_levels, radius):
+    """Per-level gradients of the geometry pyramid (reference layout rows (n*C+c, D>>i)) and of the
+    init-correlation pyramid (rows (n, W2>>i)) from the gradient of one lookup's output."""
+    gout, disp, coords = _c(gout), _c(disp), _c(coords)
+    B, _, H, W = disp.shape
+    N = B * H * W
+    ggeo = [np.zeros((N * C, D >> i), np.float32) for i in range(num_levels)]
+    ginit = [np.zeros((N, W2 >> i), np.float32) for i in range(num_levels)]
+    lib().orc_geo_lookup_bwd(_p(gout), _p(disp), _p(coords), _pp(ggeo), _pp(ginit), B, C, D, H, W, W2, num_levels, radius)
+    return ggeo, ginit

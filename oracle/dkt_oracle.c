@@ -604,4 +604,45 @@ void orc_context_upsample(const float *disp, const float *wts, float *out, int B
             }
 }
 
-int orc_version(void) { return 4; }
+
+/* Backward of the IGEV geometry-volume lookup (autograd of geometry.py:34-58 w.r.t. the two pyramids;
+ * disp is detached by the caller, igev_stereo.py:200).  Reference layouts: ggeo[i] rows (n*C + c, D>>i),
+ * ginit[i] rows (n, W2>>i); both zeroed by the caller.  Taps in k order, like orc_corr1d_lookup_bwd. */
+void orc_geo_lookup_bwd(const float *gout, const float *disp, const float *coords,
+                        float *const *ggeo, float *const *ginit,
+                        int B, int C, int D, int H, int W, int W2, int L, int r)
+{
+    const int K = 2 * r + 1;
+    const size_t HW = (size_t)H * W;
+    const int per_level = K * (C + 1);
+    for (int b = 0; b < B; ++b)
+        for (size_t p = 0; p < HW; ++p) {
+            const size_t n = (size_t)b * HW + p;
+            const float d = disp[n], cx = coords[n];
+            int di = D, wi = W2;
+            float div = 1.0f;
+            for (int i = 0; i < L; ++i) {
+                const float dl = d / div, cl = cx / div;
+                for (int c = 0; c <= C; ++c) {
+                    const int width = c < C ? di : wi;
+                    float *row = c < C ? ggeo[i] + (n * C + c) * (size_t)di : ginit[i] + n * (size_t)wi;
+                    const float wm1 = (float)(width - 1);
+                    for (int k = 0; k < K; ++k) {
+                        const float x = c < C ? (float)(k - r) + dl : (cl - dl) + (float)(k - r);
+                        const float xg = (2.0f * x) / wm1 - 1.0f;
+                        const float ix = (xg + 1.0f) * (wm1 / 2.0f);
+                        const float fl = floorf(ix);
+                        const float w = ix - fl, e = 1.0f - w;
+                        const float g = gout[((size_t)b * L * per_level + (size_t)i * per_level + (size_t)c * K + k) * HW + p];
+                        if (fl >= 0.0f && fl <= wm1) row[(int)fl] += g * e;
+                        if (fl + 1.0f >= 0.0f && fl + 1.0f <= wm1) row[(int)fl + 1] += g * w;
+                    }
+                }
+                di /= 2;
+                wi /= 2;
+                div *= 2.0f;
+            }
+        }
+}
+
+int orc_version(void) { return 5; }

@@ -193,6 +193,31 @@ def gen_corr_bwd(ref):
     save("corr_bwd", **out)
 
 
+def gen_geo_bwd(ref):
+    """Autograd of the reference through Combined_Geo_Encoding_Volume (IGEV flavour)."""
+    print("IGEV geometry volume backward")
+    out = {}
+    for name, c in _cases.GEO_CASES.items():
+        m1, m2, geo, disp, coords = _cases.geo_inputs(c)
+        K = 2 * c["r"] + 1
+        R = _synth.normal((c["B"], c["L"] * K * (c["C"] + 1), c["H"], c["W"]), c["seed"], "ggeo")
+        a, b, gv = T(m1).requires_grad_(True), T(m2).requires_grad_(True), T(geo).requires_grad_(True)
+        g = ref.GeoVolume(a, b, gv, num_levels=c["L"], radius=c["r"])
+        look = g(T(disp), T(coords))
+        ga, gb, gg = torch.autograd.grad(look, [a, b, gv], T(R))
+        out["%s/gm1" % name], out["%s/gm2" % name], out["%s/ggeo" % name] = ga.numpy(), gb.numpy(), gg.numpy()
+        # --- pin the C restatement: scatter + pooled-back chains (+ fp64 contractions for the features)
+        B, C, D, H, W = geo.shape
+        cg, ci = co.geo_lookup_bwd(R, disp, coords, C, D, c["W"], c["L"], c["r"])
+        tg = co.corr1d_pool_bwd(cg, 1.0).reshape(B, H, W, C, D).transpose(0, 3, 4, 1, 2)      # (n*C+c, D) -> (B,C,D,H,W)
+        pin("c.geo_lookup_bwd+pool_bwd.geo[%s]" % name, tg, gg.numpy(), 0.0)
+        t0 = co.corr1d_pool_bwd(ci, 1.0)
+        cf1, cf2 = co.corr1d_build_bwd(t0, m1, m2)
+        pin("c.geo_bwd.m1[%s]" % name, cf1, ga.numpy(), 4e-6 * max(float(np.abs(ga.numpy()).max()), 1.0))
+        pin("c.geo_bwd.m2[%s]" % name, cf2, gb.numpy(), 4e-6 * max(float(np.abs(gb.numpy()).max()), 1.0))
+    save("geo_bwd", **out)
+
+
 @torch.no_grad()
 def gen_pcv(ref):
     import warnings
@@ -453,7 +478,7 @@ def main():
     co.build()
     ref = _refimport.load()
     only = set(sys.argv[1:])
-    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd), ("upsample", gen_upsample), ("files", gen_files),
+    gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd), ("geo_bwd", gen_geo_bwd), ("upsample", gen_upsample), ("files", gen_files),
             ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e)]
     for name, fn in gens:
         if not only or name in only:

@@ -143,6 +143,25 @@ def test_context_upsample_oracles(name, golden, c_oracle):
     assert maxabs(c_oracle.context_upsample(disp, wts), want) <= 2e-6 * float(np.abs(want).max())
 
 
+@pytest.mark.parametrize("name", list(_cases.GEO_CASES))
+def test_geo_backward_oracle(name, golden, c_oracle):
+    """C restatement of the geometry-volume lookup backward against the reference's autograd
+    (tests/golden/geo_bwd.npz): volume gradient bit-exact, feature gradients within round-off."""
+    c = _cases.GEO_CASES[name]
+    m1, m2, geo, disp, coords = _cases.geo_inputs(c)
+    g = golden("geo_bwd")
+    K = 2 * c["r"] + 1
+    R = _synth.normal((c["B"], c["L"] * K * (c["C"] + 1), c["H"], c["W"]), c["seed"], "ggeo")
+    B, C, D, H, W = geo.shape
+    cg, ci = c_oracle.geo_lookup_bwd(R, disp, coords, C, D, c["W"], c["L"], c["r"])
+    tg = c_oracle.corr1d_pool_bwd(cg, 1.0).reshape(B, H, W, C, D).transpose(0, 3, 4, 1, 2)
+    assert np.array_equal(tg, g[name + "/ggeo"])
+    f1, f2 = c_oracle.corr1d_build_bwd(c_oracle.corr1d_pool_bwd(ci, 1.0), m1, m2)
+    for got, key in ((f1, "gm1"), (f2, "gm2")):
+        want = g["%s/%s" % (name, key)]
+        assert maxabs(got, want) <= 4e-6 * max(float(np.abs(want).max()), 1.0)
+
+
 @pytest.mark.parametrize("name", list(_cases.PCV_CASES))
 def test_pcv_oracles(name, golden, c_oracle):
     """PCVNet correlation block (meta_arch/pcvnet/corr.py): pooling by the compress factor and
