@@ -42,6 +42,14 @@ with torch.no_grad():
         x = torch.randn(1, 64, 368, 624, device=dev)
         for _ in range(reps):
             conv.conv2d(x, layer)
+    elif which == "lookup8":      # cfg4's per-GPU share: batch 8, smooth disparity (what the GRU loop produces)
+        f1, f2 = (torch.randn(8, 256, 184, 312, device=dev) for _ in range(2))
+        blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+        coords = torch.zeros(8, 2, 184, 312, device=dev)
+        xs = torch.arange(312, device=dev).float().view(1, 1, 312)
+        coords[:, 0] = xs - (10.0 + 30.0 * xs / 312) - 0.3 * torch.rand(8, 184, 312, device=dev)
+        for _ in range(reps):
+            blk(coords)
     elif which in ("lookup", "build"):
         f1, f2 = (torch.randn(1, 256, 184, 312, device=dev) for _ in range(2))
         blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
