@@ -46,18 +46,18 @@ SIGNATURES = {
     "dkt_gru_gate_out": [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _i, _i, _l, _i, _vp],
     "dkt_conv2d_packed_elems": [_ip, _i, _i, _i, _i],
     "dkt_conv2d_pack_weights": [_vp, _ip, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp],
-    "dkt_conv2d_f16s": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
+    "dkt_conv2d_f16s": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _f, _vp, _l,
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_instance_norm_stats": [_vp, _vp, _i, _l, _i, _vp],
     "dkt_instance_norm_add_relu": [_vp, _vp, _vp, _vp, _i, _l, _f, _i, _vp],
     "dkt_conv2d_stem7_packed_elems": [_i],
     "dkt_conv2d_stem7_pack": [_vp, _i, _i, _f, _vp, _vp, _i, _vp],
-    "dkt_conv2d_stem7": [_vp, _l, _vp, _vp, _vp, _f, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "dkt_conv2d_f16s_strided": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l,
+    "dkt_conv2d_stem7": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_conv2d_f16s_strided": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _f, _vp, _l,
                                 _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "dkt_conv2d_f16s_gate_zr": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
+    "dkt_conv2d_f16s_gate_zr": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
                                 _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "dkt_conv2d_f16s_gate_out": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
+    "dkt_conv2d_f16s_gate_out": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
                                  _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_direct": [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_instance_norm_workspace": [_i, _l],

@@ -14,11 +14,25 @@ Backends (``set_backend``; default "f16x3"):
   "miopen"   vendor fp32 convolution via torch (concatenates list inputs).
   "f16x2"    passes=2: activations rounded to fp16, weights split.
   "f16"      passes=1: plain fp16 operands, fp32 accumulate.
-1x1 / 3x3 layers with padding K/2 and stride 1 or 2 run on the kernel; the 7x7 stems on
-dkt_conv2d_direct; anything else on the vendor path.
+1x1 / 3x3 layers with padding K/2, stride 1 or 2, groups 1 and dilation 1 run on the kernel; the
+7x7 stems on dkt_conv2d_stem7; anything else on the vendor path.
+
+Activation range of the split-fp16 backends.  An activation x is represented as fp16 hi + fp16 lo
+of ``x * 2**layer.dkt_in_exp`` (``dkt_in_exp`` = 0 unless set): 22 significant bits for
+2^-3 <= |x * 2^e| < 65520, an ABSOLUTE resolution of 2^-25 below that (harmless next to O(1)
+activations, a loss of relative precision for tensors that are tiny throughout), and NON-FINITE
+results above it -- an out-of-range, Inf or NaN activation is never saturated silently, it shows up
+as Inf/NaN in the output (``RAFTStereo.forward`` checks its result).  Layers whose inputs live far
+from O(1) get an exponent: by hand (``layer.dkt_in_exp = -4``) or from ``calibrate()``.
+
+Thread safety (the reference drives replicas from one Python thread per GPU, tools/ft_dkt.py:119):
+the packed-weight caches are keyed per device and guarded by a lock, the backend can be overridden
+per thread (``use_backend``), nothing here mutates shared module state during a forward.
 """
+import contextlib
 import ctypes
 import math
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -27,24 +41,76 @@ from . import _ffi
 
 _PASSES = {"f16x3": 3, "f16x2": 2, "f16": 1}
 _BACKEND = "f16x3"
+_TLS = threading.local()
+_CACHE_LOCK = threading.RLock()
+
+
+def _check_backend(name):
+    if name != "miopen" and name not in _PASSES:
+        raise ValueError("unknown conv backend %r" % (name,))
 
 
 def set_backend(name):
+    """Process-wide default backend (threads may override it with ``use_backend``)."""
     global _BACKEND
-    if name != "miopen" and name not in _PASSES:
-        raise ValueError("unknown conv backend %r" % (name,))
+    _check_backend(name)
     _BACKEND = name
 
 
 def get_backend():
-    return _BACKEND
+    return getattr(_TLS, "backend", None) or _BACKEND
+
+
+@contextlib.contextmanager
+def use_backend(name):
+    """Backend override for the calling thread only."""
+    _check_backend(name)
+    prev = getattr(_TLS, "backend", None)
+    _TLS.backend = name
+    try:
+        yield
+    finally:
+        _TLS.backend = prev
+
+
+def in_exp_of(layer):
+    return int(getattr(layer, "dkt_in_exp", 0) or 0)
+
+
+@contextlib.contextmanager
+def calibrate(margin_bits=2):
+    """Records max|x| of every convolution input inside the ``with`` block (synchronising: run it
+    once, on representative inputs, outside any timed region or stream capture) and sets
+    ``layer.dkt_in_exp`` so that the largest activation seen lands ``margin_bits`` binades below the
+    fp16 limit.  Layers whose inputs are already comfortably inside [2^-3, 2^13] keep exponent 0."""
+    rec = {}
+    _TLS.calib = rec
+    try:
+        yield rec
+    finally:
+        _TLS.calib = None
+        for layer, amax in rec.values():
+            if not (amax > 0.0) or not math.isfinite(amax):
+                continue
+            e = (15 - margin_bits) - math.floor(math.log2(amax)) - 1        # amax * 2^e in [2^(14-m), 2^(15-m))
+            layer.dkt_in_exp = 0 if (-2 <= e <= 16 - margin_bits) else e
 
 
 def _vendor(x, layer, relu):
     if isinstance(x, (list, tuple)):
         x = x[0] if len(x) == 1 else torch.cat(list(x), dim=1)
-    y = F.conv2d(x, layer.weight, layer.bias, stride=_stride_of(layer), padding=layer.padding)
+    y = F.conv2d(x, layer.weight, layer.bias, stride=_stride_of(layer), padding=layer.padding,
+                 dilation=getattr(layer, "dilation", 1), groups=getattr(layer, "groups", 1))
     return torch.relu_(y) if relu else y
+
+
+def _record_range(layer, srcs):
+    rec = getattr(_TLS, "calib", None)
+    if rec is None:
+        return
+    amax = max(float(s.detach().abs().max()) for s in srcs)
+    prev = rec.get(id(layer))
+    rec[id(layer)] = (layer, amax if prev is None else max(amax, prev[1]))
 
 
 class _Packed:
@@ -52,13 +118,20 @@ class _Packed:
 
 
 def _packed_weights(layer, src_channels):
-    """Split-fp16 weight image for dkt_conv2d_f16s, cached on the layer and rebuilt
-    when the parameter tensor is replaced or written."""
+    """Split-fp16 weight image for dkt_conv2d_f16s, cached on the layer PER DEVICE (the shallow module
+    copies of nn.parallel.replicate share the cache dict; their parameters live on different devices)
+    and rebuilt when the parameter tensor is replaced or written."""
+    with _CACHE_LOCK:
+        return _packed_weights_locked(layer, src_channels)
+
+
+def _packed_weights_locked(layer, src_channels):
     w = layer.weight
     b = layer.bias
     key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(src_channels))
     cache = layer.__dict__.setdefault("_dkt_packed", {})
-    hit = cache.get(tuple(src_channels))
+    slot = (str(w.device), tuple(src_channels))
+    hit = cache.get(slot)
     if hit is not None and hit.key == key:
         return hit
     cout, cin, kh, kw = w.shape
@@ -84,19 +157,20 @@ def _packed_weights(layer, src_channels):
     p.inv_scale = 1.0 / scale
     p.bias = None if b is None else b.detach().float().contiguous()
     p.key = key
-    cache[tuple(src_channels)] = p
+    cache[slot] = p
     return p
 
 
 def clear_weight_cache(module):
     """Drops the packed fp16 weight images below `module` (needed only after writes
     that bypass the Parameter's version counter, e.g. ``weight.data.mul_()``)."""
-    for m in module.modules():
-        m.__dict__.pop("_dkt_packed", None)
-        m.__dict__.pop("_dkt_folded", None)
-        m.__dict__.pop("_dkt_stem7", None)
-        if hasattr(m, "_zr_key"):
-            m._zr_key = None
+    with _CACHE_LOCK:
+        for m in module.modules():
+            m.__dict__.pop("_dkt_packed", None)
+            m.__dict__.pop("_dkt_folded", None)
+            m.__dict__.pop("_dkt_stem7", None)
+            if hasattr(m, "_zr_cache"):
+                m._zr_cache = None
 
 
 def _dense(t):
@@ -110,21 +184,29 @@ def _stride_of(layer):
     return st
 
 
+def _plain_conv(layer):
+    """groups == 1, dilation == 1, zero padding (what the kernels implement)."""
+    dil = getattr(layer, "dilation", 1)
+    dil = (dil, dil) if isinstance(dil, int) else tuple(dil)
+    return (getattr(layer, "groups", 1) == 1 and dil == (1, 1)
+            and getattr(layer, "padding_mode", "zeros") == "zeros")
+
+
 def hip_eligible(layer):
     """True when `layer` runs on dkt_conv2d_f16s[_strided] under the current backend:
-    1x1 / 3x3, padding K/2, stride 1 or 2."""
+    1x1 / 3x3, padding K/2, stride 1 or 2, no groups / dilation."""
     kh, kw = layer.weight.shape[2:]
     pad = layer.padding
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
-    return (_BACKEND in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2)
-            and _stride_of(layer) in ((1, 1), (2, 2)))
+    return (get_backend() in _PASSES and kh == kw and kh in (1, 3) and pad == (kh // 2, kw // 2)
+            and _stride_of(layer) in ((1, 1), (2, 2)) and _plain_conv(layer))
 
 
 def direct_eligible(layer):
     """The 7x7 stems (Cin <= 4, stride 1) run on dkt_conv2d_stem7 (matrix cores, K laid out over the
     taps).  The exact-fp32 direct kernel (dkt_conv2d_direct, 26 us for 2->64 @184x312) stays available
     as _conv2d_direct."""
-    if _BACKEND not in _PASSES:
+    if get_backend() not in _PASSES or not _plain_conv(layer):
         return False
     cout, cin, kh, kw = layer.weight.shape
     pad = layer.padding
@@ -162,9 +244,27 @@ def _conv2d_stem7(x, layer, relu, out):
     B, cin, H, W = x.shape
     w, b = layer.weight, layer.bias
     cout = w.shape[0]
+    _record_range(layer, [x])
     key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
-    pk = layer.__dict__.get("_dkt_stem7")
     L = _ffi.lib()
+    with _CACHE_LOCK:
+        pk = _stem7_packed(layer, key, L)
+    in_scale = 2.0 ** in_exp_of(layer)
+    if out is None:
+        out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    rc = L.dkt_conv2d_stem7(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
+                            None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale / in_scale, in_scale,
+                            out.data_ptr(), out.stride(0), B, cin, cout, H, W, int(bool(relu)),
+                            _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_conv2d_stem7")
+    return out
+
+
+def _stem7_packed(layer, key, L):
+    w, b = layer.weight, layer.bias
+    cout, cin = w.shape[:2]
+    cache = layer.__dict__.setdefault("_dkt_stem7", {})
+    pk = cache.get(str(w.device))
     if pk is None or pk.key != key:
         wmax = float(w.detach().abs().max())
         scale = 2.0 ** (12 - math.floor(math.log2(wmax)) if wmax > 0 else 0)
@@ -179,15 +279,8 @@ def _conv2d_stem7(x, layer, relu, out):
         pk.inv_scale = 1.0 / scale
         pk.bias = None if b is None else b.detach().float().contiguous()
         pk.key = key
-        layer.__dict__["_dkt_stem7"] = pk
-    if out is None:
-        out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
-    rc = L.dkt_conv2d_stem7(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
-                            None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale,
-                            out.data_ptr(), out.stride(0), B, cin, cout, H, W, int(bool(relu)),
-                            _ffi.device_of(x), _ffi.stream_of(x))
-    _ffi.check(rc, "dkt_conv2d_stem7")
-    return out
+        cache[str(w.device)] = pk
+    return pk
 
 
 class _Operands:
@@ -200,6 +293,7 @@ class _Operands:
         _ffi.require_gpu(*srcs)
         _ffi.require_no_grad(*srcs)
         self.srcs = srcs = [s if _dense(s) else s.contiguous() for s in srcs]
+        _record_range(layer, srcs)
         self.B, _, self.H, self.W = srcs[0].shape
         chans = [int(s.shape[1]) for s in srcs]
         self.n = n = len(srcs)
@@ -211,10 +305,12 @@ class _Operands:
         self.cout = layer.weight.shape[0]
         self.bias = None if self.pk.bias is None else self.pk.bias.data_ptr()
         self.device = srcs[0].device
+        self.in_scale = 2.0 ** in_exp_of(layer)
+        self.passes = _PASSES[get_backend()]
 
     def head(self):
         return (self.ptrs, self.ch, self.bs, self.n, self.pk.hi.data_ptr(), self.pk.lo.data_ptr(),
-                self.bias, self.pk.inv_scale)
+                self.bias, self.pk.inv_scale / self.in_scale, self.in_scale)
 
 
 def conv2d(x, layer, relu=False, out=None):
@@ -239,11 +335,11 @@ def conv2d(x, layer, relu=False, out=None):
         raise ValueError("conv2d(out=...) must be a dense-per-batch fp32 tensor of the result shape")
     if stride == 1:
         rc = _ffi.lib().dkt_conv2d_f16s(*op.head(), out.data_ptr(), out.stride(0), op.B, op.H, op.W, op.cout,
-                                        op.kh, op.kw, int(bool(relu)), _PASSES[_BACKEND],
+                                        op.kh, op.kw, int(bool(relu)), op.passes,
                                         _ffi.device_of(out), _ffi.stream_of(out))
     else:
         rc = _ffi.lib().dkt_conv2d_f16s_strided(*op.head(), out.data_ptr(), out.stride(0), op.B, op.H, op.W, op.cout,
-                                                op.kh, op.kw, stride, int(bool(relu)), _PASSES[_BACKEND],
+                                                op.kh, op.kw, stride, int(bool(relu)), op.passes,
                                                 _ffi.device_of(out), _ffi.stream_of(out))
     _ffi.check(rc, "dkt_conv2d_f16s")
     return out
@@ -260,7 +356,7 @@ def conv2d_gate_zr(x, zr_layer, cz, cr, h):
     rc = _ffi.lib().dkt_conv2d_f16s_gate_zr(*op.head(), cz.data_ptr(), cz.stride(0), cr.data_ptr(), cr.stride(0),
                                             h.data_ptr(), h.stride(0), z.data_ptr(), z.stride(0),
                                             rh.data_ptr(), rh.stride(0), op.B, op.H, op.W, ch, op.kh, op.kw,
-                                            _PASSES[_BACKEND], _ffi.device_of(z), _ffi.stream_of(z))
+                                            op.passes, _ffi.device_of(z), _ffi.stream_of(z))
     _ffi.check(rc, "dkt_conv2d_f16s_gate_zr")
     return z, rh
 
@@ -274,6 +370,6 @@ def conv2d_gate_out(x, q_layer, cq, z, h, out=None):
     rc = _ffi.lib().dkt_conv2d_f16s_gate_out(*op.head(), cq.data_ptr(), cq.stride(0), z.data_ptr(), z.stride(0),
                                              h.data_ptr(), h.stride(0), out.data_ptr(), out.stride(0),
                                              op.B, op.H, op.W, op.cout, op.kh, op.kw,
-                                             _PASSES[_BACKEND], _ffi.device_of(out), _ffi.stream_of(out))
+                                             op.passes, _ffi.device_of(out), _ffi.stream_of(out))
     _ffi.check(rc, "dkt_conv2d_f16s_gate_out")
     return out

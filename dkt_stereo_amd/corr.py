@@ -190,16 +190,23 @@ class CorrBlock1D:
 class CorrBlockFast1D(CorrBlock1D):
     """core/corr.py:31-61 ("reg_cuda").  The reference needs the un-vendored
     ``corr_sampler`` CUDA extension for this class; here it is the same HIP
-    lookup as CorrBlock1D, with the reference's 5-D pyramid views."""
+    lookup as CorrBlock1D (same skewed copy, same autograd nodes -- the reference class is
+    differentiable through CorrSampler, :17-29), with the reference's 5-D pyramid views
+    in ``corr_pyramid``."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
-        super().__init__(fmap1, fmap2, num_levels=num_levels, radius=radius)
+    def rebuild(self, fmap1, fmap2):
+        self.corr_pyramid = getattr(self, "_flat", None)
+        super().rebuild(fmap1, fmap2)
         B, _, H, W1 = fmap1.shape
         self._flat = self.corr_pyramid
         self.corr_pyramid = [p.view(B, H, W1, -1, p.shape[-1]) for p in self._flat]
 
     def __call__(self, coords):
-        return _lookup(self._flat, coords, self.radius, self._w2)
+        views, self.corr_pyramid = self.corr_pyramid, self._flat
+        try:
+            return super().__call__(coords)
+        finally:
+            self.corr_pyramid = views
 
 
 class CorrBlock1D_Cosine(CorrBlock1D):
@@ -290,4 +297,7 @@ CORR_IMPLEMENTATIONS = {
     "reg_cuda": CorrBlockFast1D,
     "alt_cuda": AlternateCorrBlock,
     "cosine": CorrBlock1D_Cosine,
+    # raft_stereo.py:133-136: in test_mode "mix_fmap_image" IS the cosine block on the feature maps (the
+    # image-mixing branch, :137-142, exists only in training)
+    "mix_fmap_image": CorrBlock1D_Cosine,
 }

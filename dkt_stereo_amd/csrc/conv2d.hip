@@ -73,7 +73,8 @@ struct ConvArgs {
     const _Float16 *whi;
     const _Float16 *wlo;
     const float *bias;
-    float out_scale;  // 1/s
+    float out_scale;  // 1 / (weight scale * in_scale)
+    float in_scale;   // power of two applied to the activations before the fp16 split (range control)
     float *out;
     long out_bs;
     int H, W, Cout, CoutPad, nch16, tiles_w;
@@ -225,8 +226,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
             const int it = k >> 2, q = k & 3;
             const float v0 = (2 * q < snch && sok[it]) ? sreg[it][2 * q] : 0.0f;
             const float v1 = (2 * q + 1 < snch && sok[it]) ? sreg[it][2 * q + 1] : 0.0f;
-            const float x0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);
-            const float x1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
+            // range: |x * in_scale| must stay below 65520 (the fp16 hi part); beyond that -- and for
+            // NaN / Inf inputs -- the result is non-finite, never a silently saturated value
+            const float x0 = v0 * a.in_scale;
+            const float x1 = v1 * a.in_scale;
             const _Float16 h0_ = (_Float16)x0, h1_ = (_Float16)x1;
             shw[it][q] = pack_h2(h0_, h1_);
             if (NPLANES == 2) slw[it][q] = pack_h2((_Float16)(x0 - (float)h0_), (_Float16)(x1 - (float)h1_));
@@ -701,7 +704,7 @@ struct ConvEpilogue {
 
 static int conv2d_f16s_impl(const float *const *src, const int *src_channels, const long *src_bstride,
                             int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                            float out_scale, float *out, long out_bstride,
+                            float out_scale, float in_scale, float *out, long out_bstride,
                             int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
                             const ConvEpilogue *epi, int device, void *stream, int stride = 1) {
     if (!src || !src_channels || !src_bstride || !w_hi || !w_lo || !out) return DKT_E_NULL;
@@ -709,6 +712,7 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
     if (nsrc < 1 || nsrc > CONV_MAX_SRC || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || B > 65535) return DKT_E_SHAPE;
     if (KH != KW || (KH != 1 && KH != 3)) return DKT_E_UNSUPPORTED;
     if (passes < 1 || passes > 3) return DKT_E_UNSUPPORTED;
+    if (!(in_scale > 0.0f) || !(out_scale > 0.0f)) return DKT_E_SHAPE;
     ConvArgs a;
     for (int s = 0; s < CONV_MAX_SRC; ++s) {
         a.src[s] = s < nsrc ? src[s] : nullptr;
@@ -721,6 +725,7 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
     a.wlo = (const _Float16 *)w_lo;
     a.bias = bias;
     a.out_scale = out_scale;
+    a.in_scale = in_scale;
     a.out = out;
     a.out_bs = out_bstride;
     a.H = H; a.W = W; a.Cout = Cout;
@@ -751,25 +756,25 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
 
 extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride,
                                int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                               float out_scale, float *out, long out_bstride,
+                               float out_scale, float in_scale, float *out, long out_bstride,
                                int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
                                int device, void *stream) {
-    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, out, out_bstride,
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, in_scale, out, out_bstride,
                             B, H, W, Cout, KH, KW, relu, passes, nullptr, device, stream);
 }
 
 extern "C" int dkt_conv2d_f16s_strided(const float *const *src, const int *src_channels, const long *src_bstride,
                                        int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                                       float out_scale, float *out, long out_bstride,
+                                       float out_scale, float in_scale, float *out, long out_bstride,
                                        int B, int H, int W, int Cout, int KH, int KW, int stride, int relu,
                                        int passes, int device, void *stream) {
-    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, out, out_bstride,
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, in_scale, out, out_bstride,
                             B, H, W, Cout, KH, KW, relu, passes, nullptr, device, stream, stride);
 }
 
 extern "C" int dkt_conv2d_f16s_gate_zr(const float *const *src, const int *src_channels, const long *src_bstride,
                                        int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                                       float out_scale, const float *cz, long cz_bstride,
+                                       float out_scale, float in_scale, const float *cz, long cz_bstride,
                                        const float *cr, long cr_bstride, const float *h, long h_bstride,
                                        float *z, long z_bstride, float *rh, long rh_bstride,
                                        int B, int H, int W, int Ch, int KH, int KW, int passes,
@@ -777,13 +782,13 @@ extern "C" int dkt_conv2d_f16s_gate_zr(const float *const *src, const int *src_c
     if (!cz || !cr || !h || !z || !rh) return DKT_E_NULL;
     if (Ch <= 0 || Ch % 64 != 0) return DKT_E_UNSUPPORTED;   // z and r channels must not share a wave
     ConvEpilogue e = {1, cz, cr, h, cz_bstride, cr_bstride, h_bstride, rh, rh_bstride};
-    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, z, z_bstride,
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, in_scale, z, z_bstride,
                             B, H, W, 2 * Ch, KH, KW, 0, passes, &e, device, stream);
 }
 
 extern "C" int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_channels, const long *src_bstride,
                                         int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                                        float out_scale, const float *cq, long cq_bstride,
+                                        float out_scale, float in_scale, const float *cq, long cq_bstride,
                                         const float *z, long z_bstride, const float *h, long h_bstride,
                                         float *hout, long hout_bstride,
                                         int B, int H, int W, int Ch, int KH, int KW, int passes,
@@ -791,7 +796,7 @@ extern "C" int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_
     if (!cq || !z || !h || !hout) return DKT_E_NULL;
     if (Ch <= 0) return DKT_E_SHAPE;
     ConvEpilogue e = {2, cq, z, h, cq_bstride, z_bstride, h_bstride, nullptr, 0};
-    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, hout, hout_bstride,
+    return conv2d_f16s_impl(src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, in_scale, hout, hout_bstride,
                             B, H, W, Ch, KH, KW, 0, passes, &e, device, stream);
 }
 #endif  // CONV_TU_PASSES == 0 (ABI entry points)

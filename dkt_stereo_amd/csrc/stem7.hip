@@ -23,7 +23,7 @@ struct Stem7Args {
     long x_bs;
     const _Float16 *whi, *wlo;      // [step][coPad][16]
     const float *bias;
-    float out_scale;
+    float out_scale, in_scale;
     float *y;
     long y_bs;
     int Cin, Cout, CoutPad, H, W, tiles_w, tiles_xy, n_co;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv2d_stem7_kernel(Stem7Args a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float v = (ok && c < a.Cin) ? xb[(long)(c < a.Cin ? c : 0) * HW + off] : 0.0f;
-            v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+            v *= a.in_scale;       // power of two; out-of-range / non-finite inputs give non-finite outputs
             const _Float16 h = (_Float16)v;
             hv[c] = h;
             lv[c] = (_Float16)(v - (float)h);
@@ -143,14 +143,15 @@ extern "C" int dkt_conv2d_stem7_pack(const float *w, int Cout, int Cin, float sc
 }
 
 extern "C" int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
-                                const float *bias, float out_scale, float *y, long y_bstride,
+                                const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
                                 int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream) {
     if (!x || !w_hi || !w_lo || !y) return DKT_E_NULL;
     if (B <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || H <= 0 || W <= 0 || B > 65535) return DKT_E_SHAPE;
+    if (!(in_scale > 0.0f) || !(out_scale > 0.0f)) return DKT_E_SHAPE;
     Stem7Args a;
     a.x = x; a.x_bs = x_bstride;
     a.whi = (const _Float16 *)w_hi; a.wlo = (const _Float16 *)w_lo;
-    a.bias = bias; a.out_scale = out_scale;
+    a.bias = bias; a.out_scale = out_scale; a.in_scale = in_scale;
     a.y = y; a.y_bs = y_bstride;
     a.Cin = Cin; a.Cout = Cout; a.CoutPad = (Cout + 63) & ~63;
     a.H = H; a.W = W;

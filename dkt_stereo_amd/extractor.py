@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import conv2d
+from .conv import _CACHE_LOCK, conv2d
 
 
 def _hip_ok(x):
@@ -50,8 +50,15 @@ def _folded(conv, bn):
     """conv followed by bn (running statistics):  bn(conv(x)) = conv'(x) with
     w' = w * g, b' = (b - mean) * g + beta, g = gamma / sqrt(var + eps)  (per output channel).
     Cached on the conv module; rebuilt when any of the tensors is replaced or written."""
+    with _CACHE_LOCK:
+        return _folded_locked(conv, bn)
+
+
+def _folded_locked(conv, bn):
     key = tuple(_tensor_key(t) for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var))
-    hit = conv.__dict__.get("_dkt_folded")
+    cache = conv.__dict__.setdefault("_dkt_folded", {})      # per device: replicas share this dict
+    slot = str(conv.weight.device)
+    hit = cache.get(slot)
     if hit is not None and hit.key == key:
         return hit
     with torch.no_grad():
@@ -68,7 +75,7 @@ def _folded(conv, bn):
     f.padding = conv.padding
     f.stride = conv.stride
     f.key = key
-    conv.__dict__["_dkt_folded"] = f
+    cache[slot] = f
     return f
 
 

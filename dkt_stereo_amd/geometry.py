@@ -20,14 +20,15 @@ from . import _ffi
 from .corr import _BuildFn, _build_pyramid
 
 
-def _pool_geo(geo_volume, num_levels):
-    """(B,C,D,H,W) -> list of num_levels levels, level i = pairwise mean along D of level i-1 (geometry.py:23-25)."""
+def _pool_geo(geo_volume, num_levels, out=None):
+    """(B,C,D,H,W) -> list of num_levels levels, level i = pairwise mean along D of level i-1 (geometry.py:23-25).
+    `out`: a previous result of the same shapes whose levels >= 1 are overwritten."""
     b, c, d, h, w = geo_volume.shape
     pyr = [geo_volume]
-    for _ in range(1, num_levels):
+    for i in range(1, num_levels):
         src = pyr[-1]
         di = src.shape[2]
-        dst = torch.empty((b, c, di // 2, h, w), device=src.device, dtype=torch.float32)
+        dst = out[i] if out is not None else torch.empty((b, c, di // 2, h, w), device=src.device, dtype=torch.float32)
         rc = _ffi.lib().dkt_pool_d(src.data_ptr(), dst.data_ptr(), b * c, di, h * w, _ffi.device_of(src), _ffi.stream_of(src))
         _ffi.check(rc, "dkt_pool_d")
         pyr.append(dst)
@@ -87,21 +88,63 @@ class Combined_Geo_Encoding_Volume:
     def __init__(self, init_fmap1, init_fmap2, geo_volume, num_levels=2, radius=4):
         self.num_levels = num_levels
         self.radius = radius
+        self.init_corr_pyramid = None
+        self.geo_volume_pyramid = None
+        self._owns_level0 = False
+        self.rebuild(init_fmap1, init_fmap2, geo_volume)
+
+    def rebuild(self, init_fmap1, init_fmap2, geo_volume):
+        """(Re)computes both pyramids.  With the shapes of the previous build and no autograd involved the
+        existing tensors are overwritten in place, so a captured HIP graph of the lookup (igev_loop) keeps
+        its pointers -- the counterpart of CorrBlock1D.rebuild."""
+        num_levels = self.num_levels
         _ffi.require_gpu(init_fmap1, init_fmap2, geo_volume)
         geo_volume = geo_volume.float().contiguous()
         b, c, d, h, w = geo_volume.shape
-        self._shape = (b, c, d, h, w)
-        self._w2 = init_fmap2.shape[3]
+        shape = (b, c, d, h, w)
+        w2 = init_fmap2.shape[3]
         grad = torch.is_grad_enabled()
+        f_grad = grad and (init_fmap1.requires_grad or init_fmap2.requires_grad)
+        g_grad = grad and geo_volume.requires_grad
+        reuse = (self.geo_volume_pyramid is not None and not f_grad and not g_grad
+                 and shape == getattr(self, "_shape", None) and w2 == getattr(self, "_w2", None)
+                 and not any(t.requires_grad for t in self.geo_volume_pyramid + self.init_corr_pyramid))
+        self._shape = shape
+        self._w2 = w2
         # all-pairs correlation WITHOUT the 1/sqrt(C) of RAFT (geometry.py:62-69)
-        if grad and (init_fmap1.requires_grad or init_fmap2.requires_grad):
+        if f_grad:
             self.init_corr_pyramid = list(_BuildFn.apply(init_fmap1.float(), init_fmap2.float(), num_levels, 1.0))
         else:
-            self.init_corr_pyramid = _build_pyramid(init_fmap1.float(), init_fmap2.float(), num_levels, 1.0)
-        if grad and geo_volume.requires_grad:
+            self.init_corr_pyramid = _build_pyramid(init_fmap1.float(), init_fmap2.float(), num_levels, 1.0,
+                                                    out=self.init_corr_pyramid if reuse else None)
+        if g_grad:
             self.geo_volume_pyramid = list(_GeoPyramidFn.apply(geo_volume, num_levels))
+            self._owns_level0 = False
+        elif reuse:
+            self.own_buffers()
+            self.geo_volume_pyramid[0].copy_(geo_volume)
+            _pool_geo(self.geo_volume_pyramid[0], num_levels, out=self.geo_volume_pyramid)
         else:
             self.geo_volume_pyramid = _pool_geo(geo_volume, num_levels)
+            self._owns_level0 = False
+
+    def own_buffers(self):
+        """Level 0 of the geometry pyramid is the caller's tensor after a fresh build; this replaces it
+        by a private copy (once), so that later in-place refills never write into the caller's tensor.
+        Call it BEFORE capturing a graph of the lookup: it changes the level-0 pointer."""
+        if not self._owns_level0:
+            self.geo_volume_pyramid[0] = self.geo_volume_pyramid[0].detach().clone()
+            self._owns_level0 = True
+
+    def copy_from(self, other):
+        """Takes over the pyramids of another volume of the same shapes by device copies into the
+        existing tensors (pointers stay valid for a captured graph)."""
+        if (other._shape, other._w2, other.num_levels, other.radius) != (self._shape, self._w2, self.num_levels, self.radius):
+            raise ValueError("Combined_Geo_Encoding_Volume.copy_from: shapes differ")
+        self.own_buffers()
+        for dst, src in zip(self.geo_volume_pyramid + self.init_corr_pyramid,
+                            other.geo_volume_pyramid + other.init_corr_pyramid):
+            dst.copy_(src.detach())
 
     def _lookup(self, disp, coords, geo_pyr, init_pyr):
         b, c, d, h, w = self._shape

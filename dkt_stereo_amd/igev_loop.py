@@ -13,16 +13,27 @@ after it) -- every GRU sees the inputs the sequential order gives it, results ar
 plain loop.  The feature / 3-D aggregation networks that produce the inputs are not part of this
 library.
 """
+import weakref
+
 import torch
 
-from .update import _side_stream
+from . import conv as _conv
+from .update import FUSE_GATES, _side_stream, capture_graph, harness
 
 
 def _plain(update_block, geo_fn, disp, coords, net_list, inp_list, iters):
+    """igev_stereo.py:199-210 as written, including the slow-fast schedule (:204-207): with
+    ``slow_fast_gru`` the coarsest GRU (3 layers) and then the coarsest + middle GRUs are advanced
+    before every full update."""
     n = update_block.args.n_gru_layers
+    slow_fast = getattr(update_block.args, "slow_fast_gru", False)
     mask = None
     for itr in range(iters):
         geo_feat = geo_fn(disp, coords)
+        if n == 3 and slow_fast:
+            net_list = update_block(net_list, inp_list, iter16=True, iter08=False, iter04=False, update=False)
+        if n >= 2 and slow_fast:
+            net_list = update_block(net_list, inp_list, iter16=(n == 3), iter08=True, iter04=False, update=False)
         net_list, mask, delta = update_block(net_list, inp_list, geo_feat, disp, iter16=(n == 3), iter08=(n >= 2),
                                              need_mask=(itr == iters - 1))
         disp = disp + delta
@@ -33,32 +44,24 @@ class _State:
     pass
 
 
-def _body(ub, geo_fn, st, need_mask, last):
+def _body(ub, st, need_mask, last):
     """One iteration on static buffers.  Precondition (pipelined form): st.net[2] already holds this
     iteration's coarsest GRU update."""
     dev = st.disp.device
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     nets = list(st.net)
-    ub.inplace_state = True
-    saved = ub.side_stream
-    ub.side_stream = False
     done_mid = torch.cuda.Event()
-    try:
+    with harness(inplace_state=True, side_stream=False, before_fine=lambda: main.wait_event(done_mid)):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ub(nets, st.inp, iter04=False, iter08=True, iter16=False, update=False)        # mid GRU (i)
             done_mid.record(side)
             if not last:
                 ub(nets, st.inp, iter04=False, iter08=False, iter16=True, update=False)    # coarse GRU (i+1)
-        geo_feat = geo_fn(st.disp, st.coords)
-        ub.before_fine = lambda: main.wait_event(done_mid)
+        geo_feat = st.geo_fn(st.disp, st.coords)
         nets, mask, delta = ub(nets, st.inp, geo_feat, st.disp, iter16=False, iter08=False, need_mask=need_mask)
         main.wait_stream(side)
-    finally:
-        ub.before_fine = None
-        ub.side_stream = saved
-        ub.inplace_state = False
     st.disp.add_(delta)
     for dst, src in zip(st.net, nets):
         if dst is not src:
@@ -66,22 +69,40 @@ def _body(ub, geo_fn, st, need_mask, last):
     return mask
 
 
+def _fingerprint(update_block):
+    """Everything a captured iteration holds pointers to through a cached derivative (packed weight
+    images, merged z|r weights, biases): a changed parameter or backend must force a new capture."""
+    fp = [(_conv.get_backend(), FUSE_GATES)]
+    for t in update_block.parameters():
+        fp.append((t.data_ptr(), t._version))
+    return tuple(fp)
+
+
 @torch.no_grad()
 def igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph=True, cache=None):
     """Returns (disp, mask_feat_4, net_list) after `iters` refinement iterations.
-    `cache` (a dict the caller keeps, e.g. on its model) lets consecutive calls with the same shapes reuse
-    the captured graph; without it every call captures anew."""
+    `cache` (a dict the caller keeps, e.g. on its model) lets consecutive calls with the same shapes and
+    weights reuse the captured graph (a new geometry volume of the same shapes is copied into the cached
+    one's buffers; to avoid that copy keep ONE volume and call its ``rebuild``); without `cache` every call
+    captures anew.  ``slow_fast_gru`` runs the plain loop (igev_stereo.py:204-207)."""
     n = update_block.args.n_gru_layers
     pipelined = (use_hip_graph and init_disp.is_cuda and iters >= 3 and n == 3
                  and not getattr(update_block.args, "slow_fast_gru", False) and update_block.side_stream)
     if not pipelined:
         return _plain(update_block, geo_fn, init_disp, coords, list(net_list), inp_list, iters)
-    key = (init_disp.device, tuple(init_disp.shape), id(update_block), id(geo_fn))
+    key = (init_disp.device, tuple(init_disp.shape), tuple(geo_fn._shape), geo_fn._w2, geo_fn.num_levels,
+           geo_fn.radius, _fingerprint(update_block))
     st = cache.get("state") if cache is not None else None
-    if st is None or st.key != key:
+    if st is None or st.key != key or st.ub() is not update_block:
         st = _State()
         st.key = key
+        st.ub = weakref.ref(update_block)
         st.graph = None
+        # the state keeps the geometry volume alive (the graph holds pointers into its pyramids); a new
+        # volume of the same shapes -- the reference builds one per pair -- is copied into these buffers
+        st.geo_fn = geo_fn
+        if cache is not None:
+            geo_fn.own_buffers()                     # before the capture: changes the level-0 pointer
         st.disp = init_disp.clone()
         st.coords = coords.clone()
         st.net = [t.clone() for t in net_list]
@@ -89,6 +110,8 @@ def igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, it
         if cache is not None:
             cache["state"] = st
     else:
+        if geo_fn is not st.geo_fn:
+            st.geo_fn.copy_from(geo_fn)
         st.disp.copy_(init_disp)
         st.coords.copy_(coords)
         for dst, src in zip(st.net, net_list):
@@ -97,21 +120,18 @@ def igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, it
             for dst, src in zip(ds, ss):
                 dst.copy_(src)
     ub = update_block
-    ub.inplace_state = True
-    try:                                             # prologue: coarsest GRU of iteration 0
+    with harness(inplace_state=True):                # prologue: coarsest GRU of iteration 0
         ub(list(st.net), st.inp, iter04=False, iter08=False, iter16=True, update=False)
-    finally:
-        ub.inplace_state = False
     done = 0
     if st.graph is None:
-        _body(ub, geo_fn, st, False, False)          # eager once: packs weights, sizes the allocator
+        _body(ub, st, False, False)                  # eager once: packs weights, sizes the allocator
         done = 1
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            _body(ub, geo_fn, st, False, False)
+        with capture_graph(g):
+            _body(ub, st, False, False)
         st.graph = g                                 # (capturing records, it does not execute)
     for _ in range(iters - 1 - done):
         st.graph.replay()
-    mask = _body(ub, geo_fn, st, True, True)
+    mask = _body(ub, st, True, True)
     return st.disp.clone(), mask, [t.clone() for t in st.net]

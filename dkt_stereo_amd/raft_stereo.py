@@ -13,6 +13,8 @@ call convention (tools/evaluate_stereo.py:129).  Only ``test_mode=True`` is
 implemented: the HIP operators are inference-only.
 """
 import os
+import threading
+import weakref
 from types import SimpleNamespace
 
 import torch
@@ -23,7 +25,8 @@ from . import _ffi
 from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
 from .extractor import BasicEncoder, MultiBasicEncoder
-from .update import BasicMultiUpdateBlock, _side_stream
+from .update import FUSE_GATES, BasicMultiUpdateBlock, _side_stream, capture_graph, harness
+from . import conv as _conv
 from .utils import coords_grid
 
 #: configs/raft_stereo/base.json of the reference
@@ -39,7 +42,28 @@ def make_args(**overrides):
     return SimpleNamespace(**cfg)
 
 
+#: module -> {thread id: captured-iteration state}.  Kept outside the module (graphs and static buffers
+#: are neither picklable nor deep-copyable) and per thread (two threads driving one module each need
+#: their own static buffers and capture).
+_GRAPH_STATES = weakref.WeakKeyDictionary()
+_GRAPH_LOCK = threading.Lock()
+
+
 class RAFTStereo(nn.Module):
+    @property
+    def _graph_state(self):
+        with _GRAPH_LOCK:
+            return _GRAPH_STATES.get(self, {}).get(threading.get_ident())
+
+    @_graph_state.setter
+    def _graph_state(self, st):
+        with _GRAPH_LOCK:
+            per = _GRAPH_STATES.setdefault(self, {})
+            if st is None:
+                per.pop(threading.get_ident(), None)
+            else:
+                per[threading.get_ident()] = st
+
     def __init__(self, args=None):
         super().__init__()
         self.args = args = args if args is not None else make_args()
@@ -117,16 +141,14 @@ class RAFTStereo(nn.Module):
         corr = corr_fn(coords1)
         flow = coords1 - coords0
         nets = list(net_state)
-        if n == 3 and args.slow_fast_gru:
-            nets = self.update_block(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)
-        if n >= 2 and args.slow_fast_gru:
-            nets = self.update_block(nets, inp_list, iter32=(n == 3), iter16=True, iter08=False, update=False)
-        self.update_block.inplace_state = True     # net_state tensors are private to this loop
-        try:
+        with harness(inplace_state=True):
+            if n == 3 and args.slow_fast_gru:
+                nets = self.update_block(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+            if n >= 2 and args.slow_fast_gru:
+                nets = self.update_block(nets, inp_list, iter32=(n == 3), iter16=True, iter08=False, update=False)
+        with harness(inplace_state=True):          # net_state tensors are private to this loop
             nets, up_mask, delta_flow = self.update_block(nets, inp_list, corr, flow, iter32=(n == 3),
                                                           iter16=(n >= 2), need_mask=need_mask)
-        finally:
-            self.update_block.inplace_state = False
         # stereo: project onto the epipolar line (raft_stereo.py:165-166: delta_flow[:,1] = 0; coords1 += delta)
         # -- one launch: only the x plane changes (y + 0.0 is y)
         coords1[:, :1].add_(delta_flow[:, :1])
@@ -149,6 +171,17 @@ class RAFTStereo(nn.Module):
         return (self.pipeline_grus and a.n_gru_layers == 3 and not a.slow_fast_gru
                 and self.update_block.side_stream)
 
+    def _weights_fingerprint(self):
+        """(data_ptr, version) of every tensor the captured iteration reads through a cached derivative."""
+        fp = [(_conv.get_backend(), FUSE_GATES)]
+        for t in self.update_block.parameters():
+            fp.append((t.data_ptr(), t._version))
+        for m in self.update_block.modules():
+            e = getattr(m, "dkt_in_exp", None)
+            if e:
+                fp.append(("in_exp", id(m), e))
+        return tuple(fp)
+
     def _one_iteration_pipelined(self, corr_fn, coords0, coords1, net_state, inp_list, need_mask, last):
         """raft_stereo.py:146-167 with the two coarse GRUs off the critical path.  Precondition:
         net_state[2] already holds gru32 of THIS iteration (prologue / previous call); unless
@@ -158,12 +191,11 @@ class RAFTStereo(nn.Module):
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         nets = list(net_state)
-        ub.inplace_state = True
-        saved_side = ub.side_stream
-        ub.side_stream = False                       # the fork/join is done here
-        ub.encoder.branch_streams = self.branch_streams   # the encoder runs on `main`: its fork is not nested
         done16 = torch.cuda.Event()
-        try:
+        # the fork / join is done here (side_stream=False); the encoder runs on `main`, so its own
+        # fork (branch_streams) is not nested inside another forked stream
+        with harness(inplace_state=True, side_stream=False, branch_streams=self.branch_streams,
+                     before_fine=lambda: main.wait_event(done16)):
             side.wait_stream(main)                   # fork
             with torch.cuda.stream(side):
                 ub(nets, inp_list, iter32=False, iter16=True, iter08=False, update=False)      # gru16(i)
@@ -172,15 +204,9 @@ class RAFTStereo(nn.Module):
                     ub(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)  # gru32(i+1)
             corr = corr_fn(coords1)
             flow = coords1 - coords0
-            ub.before_fine = lambda: main.wait_event(done16)
             nets, up_mask, delta_flow = ub(nets, inp_list, corr, flow, iter32=False, iter16=False,
                                            need_mask=need_mask)
             main.wait_stream(side)                   # join
-        finally:
-            ub.before_fine = None
-            ub.encoder.branch_streams = False
-            ub.side_stream = saved_side
-            ub.inplace_state = False
         # stereo: project onto the epipolar line (raft_stereo.py:165-166: delta_flow[:,1] = 0; coords1 += delta)
         # -- one launch: only the x plane changes (y + 0.0 is y)
         coords1[:, :1].add_(delta_flow[:, :1])
@@ -194,8 +220,12 @@ class RAFTStereo(nn.Module):
         captured HIP graph (~60 launches per iteration leave the CPU out of the loop)."""
         args = self.args
         b, _, h, w = net_list[0].shape
-        key = (fmap1.device, tuple(fmap1.shape), tuple(fmap2.shape))
-        st = getattr(self, "_graph_state", None)
+        # The captured graph bakes in device pointers to the packed weight images, the merged z|r
+        # weights and the biases, all of which are re-created when a parameter is replaced or written
+        # (load_state_dict, .to(), optimiser steps) or the conv backend changes: those are part of the key.
+        key = (fmap1.device, tuple(fmap1.shape), tuple(fmap2.shape), args.corr_implementation,
+               self._weights_fingerprint())
+        st = self._graph_state
         if st is None or st["key"] != key:
             st = dict(key=key, graph=None)
             st["corr"] = CORR_IMPLEMENTATIONS[args.corr_implementation](
@@ -217,12 +247,8 @@ class RAFTStereo(nn.Module):
             st["coords1"].add_(flow_init)
         if self._can_pipeline():
             # prologue: gru32 of iteration 0 (the reference runs it first in every iteration)
-            ub = self.update_block
-            ub.inplace_state = True
-            try:
-                ub(list(st["net"]), st["inp"], iter32=True, iter16=False, iter08=False, update=False)
-            finally:
-                ub.inplace_state = False
+            with harness(inplace_state=True):
+                self.update_block(list(st["net"]), st["inp"], iter32=True, iter16=False, iter08=False, update=False)
             step = lambda mask: self._one_iteration_pipelined(st["corr"], st["coords0"], st["coords1"],  # noqa: E731
                                                               st["net"], st["inp"], mask, last=mask)
         else:
@@ -234,7 +260,7 @@ class RAFTStereo(nn.Module):
             done = 1
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with capture_graph(g):
                 step(False)
             st["graph"] = g
         for _ in range(iters - 1 - done):
@@ -275,9 +301,20 @@ class RAFTStereo(nn.Module):
         flow_up = self.upsample_flow(coords1 - coords0, up_mask)[:, :1]
         return coords1 - coords0, flow_up
 
+    #: forward() verifies that its result is finite (one host sync per call).  The split-fp16
+    #: convolutions turn an out-of-range activation (|x * 2^dkt_in_exp| >= 65520), Inf or NaN into a
+    #: non-finite output instead of saturating it; this is where that becomes an error.
+    check_finite = True
+
     @torch.no_grad()
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
         if not test_mode:
             raise NotImplementedError("dkt_stereo_amd.RAFTStereo is the inference (test_mode=True) path")
         fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
-        return self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+        flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+        if self.check_finite and not bool(torch.isfinite(flow_up).all()):
+            raise _ffi.DktError(
+                "RAFTStereo.forward produced non-finite disparities: an activation left the range of the "
+                "split-fp16 convolutions (or the inputs were not finite).  Run one forward under "
+                "dkt_stereo_amd.conv.calibrate() to set per-layer exponents, or use conv.set_backend('miopen').")
+        return flow, flow_up

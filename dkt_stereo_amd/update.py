@@ -11,14 +11,17 @@ published checkpoints load with ``strict=True``:
 
 What differs from the reference is how a GRU step is evaluated (core/update.py:23-32):
   * convz and convr run as ONE convolution with concatenated output channels;
-  * the gate arithmetic is two fused HIP kernels (dkt_gru_gate_zr / _out) instead
-    of ~12 elementwise launches;
-  * r*h is written in place into the [h | x] buffer, so of the reference's three
-    torch.cat copies per GRU only the first remains.
+  * default path: the gate arithmetic lives in the convolution epilogues
+    (dkt_conv2d_f16s_gate_zr / _gate_out): two launches per GRU, no z|r / q pre-activation
+    tensors, and the reference's torch.cat operands are read in place;
+  * DKT_FUSE_GATES=0 or the vendor-convolution backend: two streaming gate kernels
+    (dkt_gru_gate_zr / _out) after the convolutions instead of ~12 elementwise launches.
 Convolutions go through ``dkt_stereo_amd.conv.conv2d`` (see that module).
 Inference only.
 """
+import contextlib
 import os
+import threading
 from types import SimpleNamespace
 
 import torch
@@ -26,7 +29,43 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import conv2d, conv2d_gate_out, conv2d_gate_zr, get_backend, hip_eligible
+from .conv import _CACHE_LOCK, conv2d, conv2d_gate_out, conv2d_gate_zr, get_backend, hip_eligible
+
+
+class _Harness(threading.local):
+    """Per-THREAD switches the loop harnesses (raft_stereo.RAFTStereo, igev_loop) set around their calls
+    into the update block.  They used to be attributes toggled on the module, which two threads driving
+    replicas of one module (nn.DataParallel, tools/ft_dkt.py:119) would have raced on."""
+    inplace_state = False     # GRUs overwrite their hidden-state tensors instead of allocating new ones
+    side_stream = None        # None: the module's default; False: the harness forks / joins itself
+    before_fine = None        # hook called between the motion encoder and the finest GRU
+    branch_streams = False    # motion encoder's flow branch on its own stream
+
+
+_HARNESS = _Harness()
+#: stream captures are serialised across threads and run in thread-local capture mode (another thread's
+#: allocations or launches on the same device must not invalidate a capture in progress)
+CAPTURE_LOCK = threading.Lock()
+
+
+@contextlib.contextmanager
+def capture_graph(graph):
+    with CAPTURE_LOCK:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            yield
+
+
+@contextlib.contextmanager
+def harness(**switches):
+    """with harness(inplace_state=True, ...): thread-local, restored on exit."""
+    prev = {k: getattr(_HARNESS, k) for k in switches}
+    for k, v in switches.items():
+        setattr(_HARNESS, k, v)
+    try:
+        yield _HARNESS
+    finally:
+        for k, v in prev.items():
+            setattr(_HARNESS, k, v)
 
 
 #: evaluate the GRU gates inside the convolution epilogues (dkt_conv2d_f16s_gate_zr/_out)
@@ -67,23 +106,29 @@ class ConvGRU(nn.Module):
         self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
         self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
-        self._zr_key = None
-        self._zr = None
+        self._zr_cache = None        # {device: (key, merged layer)}; shared by replicate()'s shallow copies
 
     def _merged_zr(self):
-        """convz | convr as one Conv2d-like (weight, bias) pair, rebuilt whenever
+        """convz | convr as one Conv2d-like (weight, bias) pair per device, rebuilt whenever
         either parameter tensor is replaced or written (load_state_dict, .to())."""
         wz, wr = self.convz.weight, self.convr.weight
         key = (wz.data_ptr(), wr.data_ptr(), wz._version, wr._version,
+               self.convz.bias.data_ptr(), self.convr.bias.data_ptr(),
                self.convz.bias._version, self.convr.bias._version)
-        if key != self._zr_key:
-            with torch.no_grad():
-                self._zr = SimpleNamespace(
-                    weight=torch.cat([wz, wr], dim=0).contiguous(),
-                    bias=torch.cat([self.convz.bias, self.convr.bias], dim=0).contiguous(),
-                    padding=self.convz.padding)
-            self._zr_key = key
-        return self._zr
+        with _CACHE_LOCK:
+            cache = self._zr_cache
+            if cache is None:
+                cache = self._zr_cache = {}
+            hit = cache.get(str(wz.device))
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    zr = SimpleNamespace(
+                        weight=torch.cat([wz, wr], dim=0).contiguous(),
+                        bias=torch.cat([self.convz.bias, self.convr.bias], dim=0).contiguous(),
+                        padding=self.convz.padding,
+                        dkt_in_exp=getattr(self.convz, "dkt_in_exp", 0))
+                hit = cache[str(wz.device)] = (key, zr)
+            return hit[1]
 
     def forward(self, h, cz, cr, cq, *x_list, out=None):
         """`out` (optional, may be `h`): where the new hidden state is written."""
@@ -149,13 +194,12 @@ class BasicMotionEncoder(nn.Module):
         setattr(self, self._branch[1], nn.Conv2d(64, 64, 3, padding=1))
         self.conv = nn.Conv2d(64 + 64, 128 - self._aux_ch, 3, padding=1)
 
-    #: harness switch: run the flow branch on its own stream beside the correlation branch.  Only
-    #: set when the encoder itself runs on the capture's origin stream (a fork nested inside
-    #: another forked stream crashed hipStreamEndCapture on ROCm 7.2).
-    branch_streams = False
+    # harness(branch_streams=True): the flow branch runs on its own stream beside the correlation
+    # branch.  Only set when the encoder itself runs on the capture's origin stream (a fork nested
+    # inside another forked stream crashed hipStreamEndCapture on ROCm 7.2).
 
     def forward(self, flow, corr):
-        if self.branch_streams and flow.is_cuda:
+        if _HARNESS.branch_streams and flow.is_cuda:
             cur = torch.cuda.current_stream(flow.device)
             aux = _side_stream(flow.device, slot=1)
             aux.wait_stream(cur)
@@ -212,17 +256,23 @@ def interp(x, dest):
     return y
 
 
-_SIDE_STREAMS = {}
+class _SideStreams(threading.local):
+    def __init__(self):
+        self.streams = {}
+
+
+_SIDE_STREAMS = _SideStreams()
 
 
 def _side_stream(device, slot=0):
-    """Per-device auxiliary HIP streams (slot 0: coarse GRUs / motion encoder / fnet; slot 1: the
-    flow branch of the motion encoder)."""
+    """Auxiliary HIP streams per (thread, device) (slot 0: coarse GRUs / motion encoder / fnet; slot 1:
+    the flow branch of the motion encoder).  Per thread, so that two threads running (and capturing)
+    forwards on one device never fork into the same stream."""
     idx = torch.device(device).index
     key = (idx if idx is not None else torch.cuda.current_device(), slot)
-    st = _SIDE_STREAMS.get(key)
+    st = _SIDE_STREAMS.streams.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
+        st = _SIDE_STREAMS.streams[key] = torch.cuda.Stream(device=key[0])
     return st
 
 
@@ -250,23 +300,24 @@ class BasicMultiUpdateBlock(nn.Module):
             nn.ReLU(inplace=True),
             nn.Conv2d(256, (factor ** 2) * 9, 1, padding=0))
 
-    #: harness switch: GRUs overwrite their hidden-state tensors instead of allocating new ones
-    #: (the reference rebinds net[i] to a fresh tensor; nothing else may hold the old one)
-    inplace_state = False
-    #: run the motion encoder concurrently with gru32/gru16 on a second stream (DKT_SIDE_STREAM=0 disables)
+    #: run the motion encoder concurrently with gru32/gru16 on a second stream (DKT_SIDE_STREAM=0 disables);
+    #: a harness that forks / joins itself overrides it per thread with harness(side_stream=False)
     side_stream = os.environ.get("DKT_SIDE_STREAM", "1") != "0"
-    #: harness hook called between the motion encoder and the finest GRU (see RAFTStereo._one_iteration_pipelined)
-    before_fine = None
+    # Other per-thread harness switches (see _Harness): inplace_state -- GRUs overwrite their hidden-state
+    # tensors (the reference rebinds net[i] to a fresh tensor; nothing else may hold the old one);
+    # before_fine -- hook between the motion encoder and the finest GRU.
 
     def _gru_stack(self, net, inp, fine, mid, coarse, motion, it_fine, it_mid, it_coarse):
         n = self.args.n_gru_layers
-        o = (lambda t: t) if self.inplace_state else (lambda t: None)
+        hs = _HARNESS
+        o = (lambda t: t) if hs.inplace_state else (lambda t: None)
+        use_side = self.side_stream if hs.side_stream is None else hs.side_stream
         # The motion encoder (5 convolutions of the finest scale) does not depend on the two
         # coarse GRUs, whose small images leave most CUs idle (gru16: 115 tiles, gru32: 69, for
         # 512 resident blocks): it runs on a second HIP stream beside them and joins before
         # gru08.  Inside the captured iteration graph this is a parallel branch.
         side = main = None
-        if it_fine and (it_coarse or it_mid) and self.side_stream and net[0].is_cuda:
+        if it_fine and (it_coarse or it_mid) and use_side and net[0].is_cuda:
             main = torch.cuda.current_stream(net[0].device)
             side = _side_stream(net[0].device)
             side.wait_stream(main)              # fork
@@ -284,8 +335,8 @@ class BasicMultiUpdateBlock(nn.Module):
                 main.wait_stream(side)          # join: gru08 consumes the motion features
             else:
                 mf = motion()
-            if self.before_fine is not None:
-                self.before_fine()              # harness hook: wait for a coarse GRU running on another stream
+            if hs.before_fine is not None:
+                hs.before_fine()                # harness hook: wait for a coarse GRU running on another stream
             if n > 1:
                 net[0] = fine(net[0], *(inp[0]), mf, interp(net[1], net[0]), out=o(net[0]))
             else:

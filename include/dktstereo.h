@@ -240,14 +240,18 @@ int dkt_gru_gate_out(const float *aq, const float *cq, long cq_bstride,
  *   out[b,co,h,w] = out_scale * acc + bias[co], optional ReLU; (B,Cout,H,W) with
  *   batch stride out_bstride.
  * The weights must have been packed by dkt_conv2d_pack_weights with the SAME
- * src_channels list (scale = 1/out_scale, a power of two). */
+ * src_channels list.  Activations are multiplied by in_scale (a power of two, 1 by default in the
+ * Python layer) before they are split into fp16 parts; out_scale = 1 / (weight scale * in_scale).
+ * Range: |x * in_scale| < 65520; 22 significant bits for |x * in_scale| >= 2^-3, an absolute
+ * floor of 2^-25 below.  Out-of-range, Inf and NaN activations yield non-finite outputs (they are
+ * never saturated silently). */
 #define DKT_CONV_MAX_SRC 4
 long dkt_conv2d_packed_elems(const int *src_channels, int nsrc, int Cout, int KH, int KW);
 int dkt_conv2d_pack_weights(const float *w /* (Cout,sum(src_channels),KH,KW) */,
                             const int *src_channels, int nsrc, int Cout, int KH, int KW, float scale,
                             void *w_hi /* fp16[packed_elems] */, void *w_lo, int device, void *stream);
 int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride, int nsrc,
-                    const void *w_hi, const void *w_lo, const float *bias, float out_scale,
+                    const void *w_hi, const void *w_lo, const float *bias, float out_scale, float in_scale,
                     float *out, long out_bstride, int B, int H, int W, int Cout, int KH, int KW,
                     int relu, int passes, int device, void *stream);
 
@@ -256,7 +260,7 @@ int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long
  * INPUT size; out is (B, Cout, (H-1)/stride+1, (W-1)/stride+1). */
 int dkt_conv2d_f16s_strided(const float *const *src, const int *src_channels, const long *src_bstride,
                             int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                            float out_scale, float *out, long out_bstride,
+                            float out_scale, float in_scale, float *out, long out_bstride,
                             int B, int H, int W, int Cout, int KH, int KW, int stride, int relu,
                             int passes, int device, void *stream);
 
@@ -267,12 +271,12 @@ int dkt_conv2d_f16s_strided(const float *const *src, const int *src_channels, co
  *   gate_out: convq over [rh | x...]:  hout = (1 - z)*h + z*tanh(conv_q + cq)   (hout may alias h)
  * Ch must be a multiple of 64 for gate_zr.  Same arithmetic as dkt_gru_gate_zr/_out. */
 int dkt_conv2d_f16s_gate_zr(const float *const *src, const int *src_channels, const long *src_bstride, int nsrc,
-                            const void *w_hi, const void *w_lo, const float *bias, float out_scale,
+                            const void *w_hi, const void *w_lo, const float *bias, float out_scale, float in_scale,
                             const float *cz, long cz_bstride, const float *cr, long cr_bstride,
                             const float *h, long h_bstride, float *z, long z_bstride, float *rh, long rh_bstride,
                             int B, int H, int W, int Ch, int KH, int KW, int passes, int device, void *stream);
 int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_channels, const long *src_bstride, int nsrc,
-                             const void *w_hi, const void *w_lo, const float *bias, float out_scale,
+                             const void *w_hi, const void *w_lo, const float *bias, float out_scale, float in_scale,
                              const float *cq, long cq_bstride, const float *z, long z_bstride,
                              const float *h, long h_bstride, float *hout, long hout_bstride,
                              int B, int H, int W, int Ch, int KH, int KW, int passes, int device, void *stream);
@@ -286,7 +290,7 @@ long dkt_conv2d_stem7_packed_elems(int Cout);
 int dkt_conv2d_stem7_pack(const float *w, int Cout, int Cin, float scale, void *w_hi, void *w_lo,
                           int device, void *stream);
 int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
-                     const float *bias, float out_scale, float *y, long y_bstride,
+                     const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
                      int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream);
 
 /* Direct exact-fp32 convolution (stride 1, "same" padding) for the two extreme shapes of the

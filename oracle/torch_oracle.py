@@ -397,8 +397,15 @@ def igev_iterations(sd, cfg, match_left, match_right, geo_volume, init_disp, net
     disp = init_disp
     net = list(net)
     mask = None
+    slow_fast = cfg.get('slow_fast_gru', False)
     for _ in range(iters):
         feat = geo_lookup(gp, ip, disp, coords, r)
+        if n == 3 and slow_fast:       # igev_stereo.py:204-205: coarsest GRU alone
+            net = update_block(sd, 'update_block', n, net, inp, it_coarse=True, it_mid=False, it_fine=False,
+                               update=False, igev=True)
+        if n >= 2 and slow_fast:       # igev_stereo.py:206-207: coarsest + middle GRU
+            net = update_block(sd, 'update_block', n, net, inp, it_coarse=(n == 3), it_mid=True, it_fine=False,
+                               update=False, igev=True)
         net, mask, delta = update_block(sd, 'update_block', n, net, inp, feat, disp,
                                         it_coarse=(n == 3), it_mid=(n >= 2), igev=True)
         disp = disp + delta

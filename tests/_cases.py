@@ -169,6 +169,31 @@ E2E_CASES = {
 }
 E2E_WEIGHT_SEED = 7
 
-IGEV_LOOP_CASES = {
-    "small": dict(seed=71, B=1, Cm=24, C=8, D=16, H=8, W=16, iters=3),
+# slow-fast GRU schedule (raft_stereo.py:156-159): extra coarse / mid updates before every full update
+E2E_SLOWFAST_CASES = {
+    "sf3_64x128_it6": dict(seed=4, B=1, H=64, W=128, iters=6, shift=12, n=3),
+    "sf2_64x128_it6": dict(seed=5, B=1, H=64, W=128, iters=6, shift=12, n=2),
 }
+
+IGEV_LOOP_CASES = {
+    "small": dict(seed=71, B=1, Cm=24, C=8, D=16, H=8, W=16, iters=3, n=3, slow_fast=False, stride=1),
+    # slow-fast schedule of igev_stereo.py:204-207, 3 and 2 GRU layers
+    "sf3":   dict(seed=73, B=1, Cm=24, C=8, D=16, H=8, W=16, iters=4, n=3, slow_fast=True, stride=1),
+    "sf2":   dict(seed=74, B=1, Cm=24, C=8, D=16, H=8, W=16, iters=4, n=2, slow_fast=True, stride=1),
+    # BASELINE cfg 3 shapes (736x1248 -> 184x312, 96 match channels, geometry volume 8 x 48), 32 iterations
+    "kitti": dict(seed=72, B=1, Cm=96, C=8, D=48, H=184, W=312, iters=32, n=3, slow_fast=False, stride=4),
+}
+
+
+def igev_loop_cfg(c):
+    return dict(corr_levels=2, corr_radius=4, n_downsample=2, n_gru_layers=c["n"],
+                hidden_dims=[128, 128, 128], slow_fast_gru=c["slow_fast"])
+
+
+def igev_loop_inputs(c):
+    """match features, geometry volume, initial disparity, coords, hidden states, context inputs."""
+    s, B, H, W = c["seed"], c["B"], c["H"], c["W"]
+    m1, m2, geo, disp, coords = geo_inputs(dict(c, L=2, r=4))
+    net = [np.tanh(_synth.normal((B, 128, H >> i, W >> i), s, "net%d" % i)) for i in range(3)]
+    inp = [_synth.normal((B, 384, H >> i, W >> i), s, "inp%d" % i, scale=0.5) for i in range(3)]
+    return m1, m2, geo, np.abs(disp), coords, net, inp

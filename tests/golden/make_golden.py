@@ -419,6 +419,19 @@ def gen_e2e(ref):
             MANIFEST["reference_reg_vs_alt_max_abs"] = d
             out["%s/flow_up_alt" % name] = alt_up.numpy()
             print("   reference reg vs alt: %.3e" % d)
+    for name, c in _cases.E2E_SLOWFAST_CASES.items():
+        over = dict(slow_fast_gru=True, n_gru_layers=c["n"])
+        m3 = ref.RAFTStereo(SimpleNamespace(**{**vars(args), **over}))
+        sd3 = _synth.torch_state_dict(_synth.shapes_of(m3), _cases.E2E_WEIGHT_SEED)
+        m3.load_state_dict(sd3, strict=True)
+        m3.eval()
+        i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+        flow_lo, flow_up = m3(T(i1), T(i2), iters=c["iters"], test_mode=True)
+        out["%s/flow_up" % name] = flow_up.numpy()
+        out["%s/flow_lo" % name] = flow_lo.numpy()[:, :1].copy()
+        o_lo, o_up = to.raft_stereo_forward(sd3, {**cfg, **over}, T(i1), T(i2), c["iters"])
+        pin("torch.raft_stereo[%s].flow_up" % name, o_up.numpy(), flow_up.numpy(), 1e-5)
+        pin("torch.raft_stereo[%s].flow_lo" % name, o_lo.numpy(), flow_lo.numpy(), 1e-5)
     save("raft_e2e", **out)
 
 
@@ -428,28 +441,31 @@ def gen_igev_loop(ref):
     out = {}
     for name, c in _cases.IGEV_LOOP_CASES.items():
         s = c["seed"]
-        cfg = dict(corr_levels=2, corr_radius=4, n_downsample=2, n_gru_layers=3,
-                   hidden_dims=[128, 128, 128], slow_fast_gru=False)
+        cfg = _cases.igev_loop_cfg(c)
+        n, slow_fast = cfg["n_gru_layers"], cfg["slow_fast_gru"]
         args = SimpleNamespace(**cfg)
         blk = ref.igev_update.BasicMultiUpdateBlock(args, hidden_dims=cfg["hidden_dims"])
         sd = _load(blk, s, "update_block.")
-        gc = dict(c, L=2, r=4)
-        m1, m2, geo, disp, coords = _cases.geo_inputs(gc)
-        B, H, W = c["B"], c["H"], c["W"]
-        net = [np.tanh(_synth.normal((B, 128, H >> i, W >> i), s, "net%d" % i)) for i in range(3)]
-        inp = [_synth.normal((B, 384, H >> i, W >> i), s, "inp%d" % i, scale=0.5) for i in range(3)]
+        m1, m2, geo, disp0, coords, net, inp = _cases.igev_loop_inputs(c)
         tnet = [T(x.copy()) for x in net]
         tinp = [list(T(x).split(128, dim=1)) for x in inp]
         # the loop of igev_stereo.py:192-210, written against the reference's own classes
         geo_fn = ref.GeoVolume(T(m1), T(m2), T(geo), radius=4, num_levels=2)
-        d = T(np.abs(disp))
+        d = T(disp0)
         for _ in range(c["iters"]):
             feat = geo_fn(d, T(coords))
-            tnet, mask, delta = blk(tnet, tinp, feat, d, iter16=True, iter08=True)
+            if n == 3 and slow_fast:
+                tnet = blk(tnet, tinp, iter16=True, iter08=False, iter04=False, update=False)
+            if n >= 2 and slow_fast:
+                tnet = blk(tnet, tinp, iter16=(n == 3), iter08=True, iter04=False, update=False)
+            tnet, mask, delta = blk(tnet, tinp, feat, d, iter16=(n == 3), iter08=(n >= 2))
             d = d + delta
+        st = c["stride"]
         out["%s/disp" % name] = d.numpy()
-        out["%s/mask" % name] = mask.numpy()
-        od, om = to.igev_iterations(sd, cfg, T(m1), T(m2), T(geo), T(np.abs(disp)),
+        out["%s/mask" % name] = mask.numpy()[:, :, ::st, ::st].copy()
+        out["%s/mask_stride" % name] = np.int64(st)
+        print("   %s: disparity range %.2f .. %.2f" % (name, float(d.min()), float(d.max())))
+        od, om = to.igev_iterations(sd, cfg, T(m1), T(m2), T(geo), T(disp0),
                                     [T(x.copy()) for x in net], tinp, c["iters"])
         pin("torch.igev_iterations[%s].disp" % name, od.numpy(), d.numpy(), 0.0)
         pin("torch.igev_iterations[%s].mask" % name, om.numpy(), mask.numpy(), 0.0)

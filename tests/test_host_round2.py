@@ -1,0 +1,143 @@
+"""CPU tests (no GPU): oracle vs the slow-fast fixtures, host-side logic added in round 2
+(thread-local harness switches and backend override, per-device weight caches, InputPadder)."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import _cases
+import _synth
+from oracle import torch_oracle as to
+
+T = torch.from_numpy
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+@pytest.mark.parametrize("name", ["small", "sf3", "sf2"])
+def test_igev_loop_oracle_all_schedules(name, golden):
+    """igev_stereo.py:199-210 incl. the slow-fast schedule (:204-207), 3 and 2 GRU layers."""
+    from test_layout import update_block_shapes
+    c = _cases.IGEV_LOOP_CASES[name]
+    cfg = _cases.igev_loop_cfg(c)
+    shapes = update_block_shapes(True, cfg)
+    sd = _synth.torch_state_dict({"update_block." + k: v for k, v in shapes.items()}, c["seed"])
+    m1, m2, geo, disp0, coords, net, inp = _cases.igev_loop_inputs(c)
+    tinp = [list(T(x).split(128, dim=1)) for x in inp]
+    d, m = to.igev_iterations(sd, cfg, T(m1), T(m2), T(geo), T(disp0), [T(x) for x in net], tinp, c["iters"])
+    g = golden("igev_loop")
+    assert maxabs(d.numpy(), g[name + "/disp"]) <= 1e-4
+    assert maxabs(m.numpy(), g[name + "/mask"]) <= 1e-4
+
+
+def test_slow_fast_changes_the_result(golden):
+    """Guards the fixtures themselves: the slow-fast schedule is not a no-op."""
+    g = golden("igev_loop")
+    assert g["sf3/disp"].shape == g["small/disp"].shape
+    a, b = _cases.IGEV_LOOP_CASES["sf3"], _cases.IGEV_LOOP_CASES["small"]
+    assert a["slow_fast"] and not b["slow_fast"]
+
+
+@pytest.mark.parametrize("name", list(_cases.E2E_SLOWFAST_CASES))
+def test_raft_slow_fast_oracle(name, golden):
+    """raft_stereo.py:156-159 with 3 and 2 GRU layers."""
+    c = _cases.E2E_SLOWFAST_CASES[name]
+    from dkt_stereo_amd.raft_stereo import BASE_CONFIG, RAFTStereo, make_args
+    over = dict(slow_fast_gru=True, n_gru_layers=c["n"])
+    shapes = _synth.shapes_of(RAFTStereo(make_args(**over)))
+    sd = _synth.torch_state_dict(shapes, _cases.E2E_WEIGHT_SEED)
+    i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+    lo, up = to.raft_stereo_forward(sd, {**BASE_CONFIG, **over}, T(i1), T(i2), c["iters"])
+    g = golden("raft_e2e")
+    assert maxabs(up.numpy(), g[name + "/flow_up"]) <= 1e-3
+    assert maxabs(lo.numpy()[:, :1], g[name + "/flow_lo"]) <= 1e-3
+
+
+def test_igev_kitti_fixture_is_pinned():
+    """The 184x312 / 32-iteration loop fixture is too slow to re-run on CPU in this suite; its pin
+    (oracle == reference, 0.0) was recorded when it was generated."""
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "MANIFEST.json")))["pins"]
+    for k in ("torch.igev_iterations[kitti].disp", "torch.igev_iterations[kitti].mask"):
+        assert pins[k]["max_abs"] <= pins[k]["bound"]
+
+
+def test_harness_switches_are_thread_local():
+    from dkt_stereo_amd.update import _HARNESS, harness
+    seen = {}
+    gate = threading.Barrier(2)
+
+    def worker(name, val):
+        with harness(inplace_state=val, side_stream=False):
+            gate.wait()
+            seen[name] = (_HARNESS.inplace_state, _HARNESS.side_stream)
+            gate.wait()
+        seen[name + "_after"] = (_HARNESS.inplace_state, _HARNESS.side_stream)
+
+    ts = [threading.Thread(target=worker, args=("a", True)), threading.Thread(target=worker, args=("b", False))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert seen["a"] == (True, False) and seen["b"] == (False, False)
+    assert seen["a_after"] == (False, None) and seen["b_after"] == (False, None)
+    assert (_HARNESS.inplace_state, _HARNESS.side_stream) == (False, None)
+
+
+def test_backend_override_is_thread_local():
+    from dkt_stereo_amd import conv
+    base = conv.get_backend()
+    got = {}
+
+    def worker():
+        got["before"] = conv.get_backend()
+        with conv.use_backend("miopen"):
+            got["inside"] = conv.get_backend()
+        got["after"] = conv.get_backend()
+
+    with conv.use_backend("f16x2"):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert conv.get_backend() == "f16x2"
+    assert conv.get_backend() == base
+    assert got == {"before": base, "inside": "miopen", "after": base}
+    with pytest.raises(ValueError):
+        conv.set_backend("fp8")
+
+
+def test_merged_zr_cache_is_per_device_and_versioned():
+    """ConvGRU's merged z|r weights: one entry per device, rebuilt when a parameter is written."""
+    from dkt_stereo_amd.update import ConvGRU
+    gru = ConvGRU(8, 8)
+    a = gru._merged_zr()
+    assert a is gru._merged_zr()
+    assert torch.equal(a.weight, torch.cat([gru.convz.weight, gru.convr.weight], 0))
+    with torch.no_grad():
+        gru.convr.bias.add_(1.0)
+    b = gru._merged_zr()
+    assert b is not a and torch.equal(b.bias[8:], gru.convr.bias)
+    assert list(gru._zr_cache) == ["cpu"]
+
+
+@pytest.mark.parametrize("dims,div,mode", [((375, 1242), 32, "kitti"), ((540, 960), 32, "sintel"), ((736, 1248), 32, "kitti"),
+                                           ((5, 7), 8, "sintel"), ((64, 64), 8, "other"), ((1, 1), 32, "sintel")])
+def test_input_padder(dims, div, mode):
+    """core/utils/utils.py:7-26: replicate padding to a multiple of divis_by, 'sintel' splits the rows,
+    every other mode pads the bottom; unpad inverts pad."""
+    from dkt_stereo_amd.utils import InputPadder
+    h, w = dims
+    x = T(_synth.normal((2, 3, h, w), 7, "pad"))
+    p = InputPadder(x.shape, mode=mode, divis_by=div)
+    # the reference's arithmetic (utils.py:10-15)
+    pad_ht = (((h // div) + 1) * div - h) % div
+    pad_wd = (((w // div) + 1) * div - w) % div
+    want = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2] if mode == "sintel" else \
+        [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+    assert p._pad == want
+    y, = p.pad(x)
+    assert y.shape[-2] % div == 0 and y.shape[-1] % div == 0
+    assert torch.equal(y, torch.nn.functional.pad(x, want, mode="replicate"))
+    assert torch.equal(p.unpad(y), x)
