@@ -282,13 +282,20 @@ def main():
         # MFMA-bound; `achieved` counts the fp16 MFMA flops it executes per launch
         # (passes x 2*H*W*Cin*9*Cout; the fp32-equivalent algorithmic figure is 1/passes of it)
         # against the dense fp16 MFMA peak.
+        # `achieved` / `frac` are ALGORITHMIC: the layer's 2*H*W*Cin*9*Cout flops (what an fp32 convolution
+        # of this shape needs) per launch over the launch time, against the dense fp16 MFMA peak the kernel
+        # issues on.  The kernel spends `mfma_passes` fp16 MFMAs per algorithmic product (split operands,
+        # fp32-class result): `mfma_issue_frac` = passes x frac is how busy it keeps the matrix pipe.
         "roofline": {"kernel": "conv2d_f16s_kernel (dkt_conv2d_f16s_gate_zr), gru08 z|r 384->256 3x3 + gate epilogue @%dx%d" % (h4, w4),
-                     "bound": "mfma", "achieved": conv_tflops_exec, "peak": FP16_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": conv_tflops_exec / FP16_MFMA_PEAK_TFLOPS,
+                     "bound": "mfma", "achieved": conv_tflops_exec / passes, "peak": FP16_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": conv_tflops_exec / passes / FP16_MFMA_PEAK_TFLOPS,
+                     "frac_algorithmic": conv_tflops_exec / passes / FP16_MFMA_PEAK_TFLOPS,
+                     "mfma_issue_frac": conv_tflops_exec / FP16_MFMA_PEAK_TFLOPS,
+                     "mfma_issued_tflops": conv_tflops_exec,
+                     "frac_of_fp32_mfma_peak": conv_tflops_exec / passes / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": traffic.get("conv_zr_gate_bytes") if default_shape else None,
                      "traffic_source": traffic.get("source") if default_shape else None,
-                     "algorithmic_flops_per_launch_fp32_equiv": conv_alg_flops, "mfma_passes": passes,
-                     "fp32_equivalent_tflops": conv_tflops_exec / passes,
+                     "algorithmic_flops_per_launch": conv_alg_flops, "mfma_passes": passes,
                      "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
@@ -297,6 +304,7 @@ def main():
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic.get("lookup_b1_bytes") if default_shape else None,
+                            "traffic_source": traffic.get("source") if default_shape else None,
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
                             "launches_timed": len(look_ms)},
     }

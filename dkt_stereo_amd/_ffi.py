@@ -19,8 +19,21 @@ _pp = ctypes.POINTER(ctypes.c_void_p)
 _ip = ctypes.POINTER(ctypes.c_int)
 _lp = ctypes.POINTER(ctypes.c_long)
 
+class ConvDesc(ctypes.Structure):
+    """dkt_conv_desc of include/dktstereo.h."""
+    _fields_ = [("src", ctypes.c_void_p * 4), ("src_bstride", ctypes.c_long * 4), ("src_channels", ctypes.c_int * 4),
+                ("nsrc", ctypes.c_int), ("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("out_scale", ctypes.c_float), ("in_scale", ctypes.c_float), ("out", ctypes.c_void_p),
+                ("out_bstride", ctypes.c_long), ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+                ("Cout", ctypes.c_int), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("relu", ctypes.c_int),
+                ("epilogue", ctypes.c_int), ("e0", ctypes.c_void_p), ("e0_bstride", ctypes.c_long),
+                ("e1", ctypes.c_void_p), ("e1_bstride", ctypes.c_long), ("h", ctypes.c_void_p),
+                ("h_bstride", ctypes.c_long), ("out2", ctypes.c_void_p), ("out2_bstride", ctypes.c_long)]
+
+
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
+    "dkt_conv2d_f16s_pair": [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _i, _i, _vp],
     "dkt_corr1d_build": [_vp, _vp, _pp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_corr1d_lookup": [_pp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_convex_upsample": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -35,6 +48,7 @@ SIGNATURES = {
     "dkt_corr1d_skew_pitch": [_i],
     "dkt_corr1d_skew": [_pp, _pp, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_corr1d_lookup_skew": [_pp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_corr1d_lookup_conv1x1": [_pp, _vp, _l, _vp, _vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_corr1d_lookup_otf": [_vp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_pool_w": [_vp, _vp, _l, _i, _i, _vp],
     "dkt_l2norm_channels": [_vp, _vp, _i, _i, _l, _i, _vp],

@@ -313,6 +313,72 @@ class _Operands:
                 self.bias, self.pk.inv_scale / self.in_scale, self.in_scale)
 
 
+def _desc(op, out, relu=False, epilogue=0, e0=None, e1=None, h=None, out2=None):
+    """dkt_conv_desc for one convolution of a paired launch (keeps `op` alive through the returned object)."""
+    d = _ffi.ConvDesc()
+    for i in range(op.n):
+        d.src[i] = op.srcs[i].data_ptr()
+        d.src_bstride[i] = op.srcs[i].stride(0)
+        d.src_channels[i] = int(op.srcs[i].shape[1])
+    d.nsrc = op.n
+    d.w_hi, d.w_lo = op.pk.hi.data_ptr(), op.pk.lo.data_ptr()
+    d.bias = op.bias
+    d.out_scale, d.in_scale = op.pk.inv_scale / op.in_scale, op.in_scale
+    d.out, d.out_bstride = out.data_ptr(), out.stride(0)
+    d.B, d.H, d.W, d.Cout, d.KH, d.KW, d.relu = op.B, op.H, op.W, op.cout, op.kh, op.kw, int(bool(relu))
+    d.epilogue = epilogue
+    for name, t in (("e0", e0), ("e1", e1), ("h", h), ("out2", out2)):
+        if t is not None:
+            setattr(d, name, t.data_ptr())
+            setattr(d, name + "_bstride", t.stride(0))
+    d._keep = (op, out, e0, e1, h, out2)
+    return d
+
+
+def pair_eligible(layer_a, layer_b):
+    """Two stride-1 layers can share a launch (dkt_conv2d_f16s_pair): same filter size, same output-width class."""
+    def cls(c):
+        return 0 if c <= 32 else 1 if c <= 64 else 2 if c <= 128 else 3
+    wa, wb = layer_a.weight, layer_b.weight
+    return (hip_eligible(layer_a) and hip_eligible(layer_b) and _stride_of(layer_a) == (1, 1) == _stride_of(layer_b)
+            and wa.shape[2] == wb.shape[2] and cls(wa.shape[0]) == cls(wb.shape[0]))
+
+
+def _launch_pair(da, db, passes, ref):
+    rc = _ffi.lib().dkt_conv2d_f16s_pair(ctypes.byref(da), ctypes.byref(db), passes, _ffi.device_of(ref), _ffi.stream_of(ref))
+    _ffi.check(rc, "dkt_conv2d_f16s_pair")
+
+
+def conv2d_gate_zr_pair(a, b):
+    """conv2d_gate_zr for two independent GRUs in one launch.  a, b = (x, zr_layer, cz, cr, h);
+    returns ((z_a, rh_a), (z_b, rh_b))."""
+    res, descs, passes = [], [], None
+    for x, zr_layer, cz, cr, h in (a, b):
+        op = _Operands(x, zr_layer)
+        ch = op.cout // 2
+        z = torch.empty((op.B, ch, op.H, op.W), device=op.device, dtype=torch.float32)
+        rh = torch.empty_like(z)
+        descs.append(_desc(op, z, epilogue=1, e0=cz, e1=cr, h=h, out2=rh))
+        res.append((z, rh))
+        passes = op.passes
+    _launch_pair(descs[0], descs[1], passes, res[0][0])
+    return res
+
+
+def conv2d_gate_out_pair(a, b):
+    """conv2d_gate_out for two independent GRUs in one launch.  a, b = (x, q_layer, cq, z, h, out)."""
+    res, descs, passes = [], [], None
+    for x, q_layer, cq, z, h, out in (a, b):
+        op = _Operands(x, q_layer)
+        if out is None:
+            out = torch.empty((op.B, op.cout, op.H, op.W), device=op.device, dtype=torch.float32)
+        descs.append(_desc(op, out, epilogue=2, e0=cq, e1=z, h=h))
+        res.append(out)
+        passes = op.passes
+    _launch_pair(descs[0], descs[1], passes, res[0])
+    return res
+
+
 def conv2d(x, layer, relu=False, out=None):
     """`out`: optional (B,Cout,H,W) fp32 destination whose batch elements are dense (e.g. a
     channel slice of a wider buffer -- replaces a torch.cat of the result)."""

@@ -133,6 +133,26 @@ class _LookupFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class DeferredLookup:
+    """``corr_fn.deferred(coords)``: stands in for the lookup tensor between the loop harness and the
+    motion encoder (which is its only consumer, core/update.py:79)."""
+
+    def __init__(self, block, coords):
+        self.block, self.coords = block, coords
+        self.device = coords.device
+
+    @property
+    def is_cuda(self):
+        return self.coords.is_cuda
+
+    def materialize(self):
+        return self.block(self.coords)
+
+    def conv1x1(self, layer, relu=True):
+        out = self.block.lookup_conv1x1(self.coords, layer, relu=relu)
+        return out
+
+
 class CorrBlock1D:
     """core/corr.py:110-156.  ``corr_pyramid`` holds the ``num_levels`` levels that
     ``__call__`` reads (the reference also stores one more pooled level that
@@ -174,6 +194,51 @@ class CorrBlock1D:
         if self._skew is not None:
             return _lookup(self._skew, coords, self.radius, self._w2, skewed=True)
         return _lookup(self.corr_pyramid, coords, self.radius, self._w2)
+
+    # ---- lookup fused with the 1x1 convolution that consumes it (dkt_corr1d_lookup_conv1x1) ----
+    def deferred(self, coords):
+        """A lookup that has not been run yet: ``BasicMotionEncoder`` turns it into
+        relu(convc1(lookup)) in ONE launch (``DeferredLookup.conv1x1``); anything else that needs the
+        tensor calls ``materialize()`` and gets exactly ``self(coords)``."""
+        return DeferredLookup(self, coords)
+
+    def lookup_conv1x1(self, coords, layer, relu=True, tap=False):
+        """relu(layer(self(coords))) for a 1x1 ``layer`` with <= 64 outputs, without ever writing the
+        lookup.  Returns None when the fused kernel does not cover this configuration (row layout,
+        unsupported L / r / layer, autograd involved): run the two steps separately then.
+        tap=True additionally returns the sampled values (bit-identical to ``self(coords)``)."""
+        w = layer.weight
+        K = 2 * self.radius + 1
+        if (self._skew is None or w.dim() != 4 or tuple(w.shape[2:]) != (1, 1) or w.shape[0] > 64
+                or w.shape[1] != self.num_levels * K or self.num_levels not in (2, 3, 4) or self.radius not in (3, 4)
+                or (self._w2 >> (self.num_levels - 1)) < 2
+                or getattr(layer, "groups", 1) != 1 or tuple(getattr(layer, "stride", (1, 1))) != (1, 1)
+                or (torch.is_grad_enabled() and (w.requires_grad or coords.requires_grad
+                                                 or any(p.requires_grad for p in self.corr_pyramid)))):
+            return None
+        _ffi.require_gpu(coords)
+        B, _, H, W1 = coords.shape
+        if coords.stride(3) != 1 or coords.stride(2) != W1:
+            coords = coords.contiguous()
+        cout = w.shape[0]
+        # the kernel wants the weight k-major, (L*K, Cout); cached on the layer per device and version
+        key = (w.data_ptr(), w._version)
+        hit = layer.__dict__.get("_dkt_wt", {}).get(str(w.device))
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().reshape(cout, -1).t().float().contiguous())
+            layer.__dict__.setdefault("_dkt_wt", {})[str(w.device)] = hit
+        wm = hit[1]
+        bias = layer.bias
+        out = torch.empty((B, cout, H, W1), device=coords.device, dtype=torch.float32)
+        tp = torch.empty((B, self.num_levels * K, H, W1), device=coords.device, dtype=torch.float32) if tap else None
+        rc = _ffi.lib().dkt_corr1d_lookup_conv1x1(
+            _ffi.ptr_array(self._skew), coords.data_ptr(), coords.stride(0), wm.data_ptr(),
+            None if bias is None else bias.detach().data_ptr(), out.data_ptr(), out.stride(0),
+            None if tp is None else tp.data_ptr(), 0 if tp is None else tp.stride(0),
+            B, H, W1, self._w2, self.num_levels, self.radius, cout, int(bool(relu)),
+            _ffi.device_of(coords), _ffi.stream_of(coords))
+        _ffi.check(rc, "dkt_corr1d_lookup_conv1x1")
+        return (out, tp) if tap else out
 
     @staticmethod
     def corr(fmap1, fmap2):

@@ -103,7 +103,8 @@ __device__ __forceinline__ float conv_sigmoid(float x) {
     return __frcp_rn(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float conv_tanh(float x) {
-    const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+    const float xc = x < -15.0f ? -15.0f : (x > 15.0f ? 15.0f : x);      // NaN passes through
+    const float t = __expf(2.0f * xc);
     return (t - 1.0f) * __frcp_rn(t + 1.0f);
 }
 
@@ -117,7 +118,16 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
 template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) void conv2d_f16s_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) void conv2d_f16s_kernel(ConvArgs a0, ConvArgs a1, int nb0) {
+    // Two independent convolutions may share one launch (dkt_conv2d_f16s_pair): blocks [0, nb0) stream
+    // the tiles of problem 0, the others those of problem 1 -- a small layer (the coarsest GRU: 36
+    // tiles) then rides in the tile-quantisation slack of a large one (the finest GRU: 460 tiles on
+    // 256 resident blocks) instead of occupying the device for a launch of its own.  The selection
+    // is block-uniform: every a.field below is a scalar load from the chosen argument block.
+    const bool second = (int)blockIdx.x >= nb0;
+    const ConvArgs &a = second ? a1 : a0;
+    const int blk_first = second ? nb0 : 0;
+    const int blk_count = second ? (int)gridDim.x - nb0 : nb0;
     constexpr int HALO = KS / 2;
     constexpr int TR = NF * WN;              // output rows per block
     // ST = 2: stride-2 convolution (the encoders' down-sampling layers).  Tiles are OUTPUT tiles;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const long HW = (long)a.H * a.W;
-    // Persistent block: tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...; the (tile, chunk)
+    // Persistent block: tiles t = (block index within its problem), + (blocks of that problem), ...; the (tile, chunk)
     // pairs of a block form ONE software-pipelined stream, so that only the block's first
     // chunk is staged with its global-load latency exposed (for a 64->64 layer -- two chunks
     // per tile -- prologue + epilogue used to be 52 of 113 us).
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
         tb = r / a.n_co;
     };
     int h0, w0, co_blk, b;            // tile being computed
-    int tile = blockIdx.x;
+    int tile = (int)blockIdx.x - blk_first;
     decode(tile, h0, w0, co_blk, b);
 
     // ---- staging.  Wave w stages channels 8w..8w+7 of every 32-channel chunk; its lanes walk
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
                     for (int r = 0; r < 16; ++r) {
                         const int dco = m * 32 + (r & 3) + 8 * (r >> 2);
                         float v = acc[m][n][r] * a.out_scale + bv[m][r];
-                        if (a.relu) v = fmaxf(v, 0.0f);
+                        if (a.relu) v = dkt_relu(v);
                         if (all_co || co_lane + dco < a.Cout) op[dco * oHW] = v;
                     }
             }
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
     loadB(0, lds, 0);
     int g = 0;                               // chunks consumed by this block: LDS buffer parity
     for (;;) {
-        const int tn = tile + (int)gridDim.x;
+        const int tn = tile + blk_count;
         const bool have_next = tn < a.total_tiles;
         int nh0 = h0, nw0 = w0, nco = co_blk, nb = b;
         if (have_next) decode(tn, nh0, nw0, nco, nb);
@@ -573,8 +583,14 @@ static int conv_slots(const void *kern, size_t lds, int dev, int threads) {
     return per_cu * cus;
 }
 
+// A second, independent convolution that shares the launch (see the kernel's head comment).
+struct ConvSecond {
+    ConvArgs a;
+    int B;
+};
+
 template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
-static int launch_conv(ConvArgs a, int B, hipStream_t st) {
+static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec = nullptr) {
     constexpr int NPP = ((NF * WN - 1) * ST + KS) * (31 * ST + KS);
     constexpr int STAGE = NPP * (8 * CK + 4) * (PASSES == 3 ? 2 : 1);
     const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);   // + dummy words for surplus staging lanes
@@ -598,8 +614,29 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
     a.total_tiles = (int)total;
     // DKT_CONV_PERSIST=0 (tuning knob): one block per tile, i.e. no cross-tile pipelining
     static const bool persist = [] { const char *e = getenv("DKT_CONV_PERSIST"); return !e || atoi(e) != 0; }();
-    const long nblk = persist && total > slots[dev & 63] ? slots[dev & 63] : total;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, a);
+    const long cap = slots[dev & 63];
+    if (!sec) {
+        const long nblk = persist && total > cap ? cap : total;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, a, a, (int)nblk);
+        return dkt_launch_status();
+    }
+    // ---- two problems: resident blocks are split in proportion to the work (tiles x chunks)
+    ConvArgs b = sec->a;
+    b.tiles_xy = b.tiles_w * ((b.Ho + NF * WN - 1) / (NF * WN));
+    b.n_co = (b.Cout + 32 * MF * WM - 1) / (32 * MF * WM);
+    const long total1 = (long)b.tiles_xy * b.n_co * sec->B;
+    if (total1 > 0x7fffffffL) return DKT_E_SHAPE;
+    b.total_tiles = (int)total1;
+    long nb0 = total, nb1 = total1;
+    if (persist && total + total1 > cap) {
+        const double w0 = (double)total * a.nch16, w1 = (double)total1 * b.nch16;
+        nb1 = (long)(cap * w1 / (w0 + w1) + 0.5);
+        nb1 = nb1 < 1 ? 1 : (nb1 > total1 ? total1 : nb1);
+        nb0 = cap - nb1;
+        if (nb0 > total) nb0 = total;
+        if (nb0 < 1) nb0 = 1;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nb0 + nb1)), dim3(64 * WM * WN), lds, st, a, b, (int)nb0);
     return dkt_launch_status();
 }
 
@@ -608,22 +645,22 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st) {
 // layers put them on rows.  Images too small to give every CU a block with 4-row
 // wave tiles use 2-row wave tiles.
 template <int KS, int PASSES>
-static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
+static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const ConvSecond *sec = nullptr) {
     const long tiles4 = (long)a.tiles_w * ((a.H + 3) / 4) * B;    // blocks if a block covers 4 rows
     static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5|6|7|8 forces a tile shape
         const char *e = getenv("DKT_CONV_CFG");
         return e ? atoi(e) : 0;
     }();
     switch (forced) {
-    case 1: return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);
-    case 2: return launch_conv<KS, 1, 4, 2, PASSES>(a, B, st);
-    case 3: return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);
-    case 5: return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);
-    case 6: return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);
-    case 7: return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);
-    case 8: return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st);
-    case 10: if constexpr (KS == 3) return launch_conv<KS, 4, 2, 2, PASSES>(a, B, st); break;
-    case 9: if constexpr (KS == 3) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st); break;
+    case 1: return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st, sec);
+    case 2: return launch_conv<KS, 1, 4, 2, PASSES>(a, B, st, sec);
+    case 3: return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st, sec);
+    case 5: return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st, sec);
+    case 6: return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st, sec);
+    case 7: return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st, sec);
+    case 8: return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st, sec);
+    case 10: if constexpr (KS == 3) return launch_conv<KS, 4, 2, 2, PASSES>(a, B, st, sec); break;
+    case 9: if constexpr (KS == 3) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st, sec); break;
     default: break;
     }
     // 4-row blocks keep the LDS stage at 65 KB, i.e. two blocks per CU; the 8-row forms
@@ -632,31 +669,31 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st) {
     // take half-height tiles so that twice as many CUs work.
     const long few = CONV_FEW_TILES;
     // the flow / disparity heads (2 and 1 output channels): a 32-channel wave tile halves the padded MFMA work
-    if (a.Cout <= 32) return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st);  // 32 co x 4 rows
+    if (a.Cout <= 32) return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st, sec);  // 32 co x 4 rows
     if (a.Cout <= 64) {
         // 64 co x 8 rows with 16-channel chunks (33 KB LDS stage: still two blocks per CU): twice the
         // MFMAs per weight fragment of the 4-row form (64->64 @368x624: 90 -> 78 us; not for images
         // that give fewer 8-row tiles than resident blocks: @184x312 29 -> 32 us)
         if constexpr (KS == 3) {
-            if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st);   // >= one full wave of blocks
+            if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st, sec);   // >= one full wave of blocks
         }
-        return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st);                          // 64 co x 4 rows
+        return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st, sec);                          // 64 co x 4 rows
     }
     if (a.Cout <= 128) {
-        if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st);        // 128 co x 2 rows
-        return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st);                          // 128 co x 4 rows
+        if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st, sec);        // 128 co x 2 rows
+        return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st, sec);                          // 128 co x 4 rows
     }
     const long tiles2 = (long)a.tiles_w * ((a.H + 1) / 2) * B * ((a.Cout + 255) / 256);
-    if (tiles2 < few) return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st);            // 256 co x 1 row
+    if (tiles2 < few) return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st, sec);            // 256 co x 1 row
     // wide layers on large images: ONE block of 8 waves per CU, 256 co x 4 rows (WM x WN = 4 x 2): the two
     // waves of a SIMD share their weight fragments through L1 and the patch halo shrinks (6 rows
     // staged per 4 instead of 4 per 2).  Measured 384->256 @184x312: 326 -> 315 us; 128->256: 113 -> 109.
     if (tiles4 * ((a.Cout + 255) / 256) >= 256) {
-        if constexpr (KS == 3) return launch_conv<KS, 4, 2, 2, PASSES>(a, B, st);
+        if constexpr (KS == 3) return launch_conv<KS, 4, 2, 2, PASSES>(a, B, st, sec);
     }
     // otherwise: 256 co x 2 rows per block, two blocks per CU.  (Measured on 384->256 @184x312:
     // 324 us vs 374 us for the 256 co x 4 rows / one-block-per-CU form.)
-    return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st);                              // 256 co x 2 rows
+    return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st, sec);                              // 256 co x 2 rows
 }
 
 // Stride-2 layers (the encoders' down-sampling convolutions, core/extractor.py:16,34,136-138):
@@ -670,27 +707,28 @@ static int launch_conv_stride2(const ConvArgs &a, int B, hipStream_t st) {
 // The kernel instantiations are split by number of MFMA passes so that the build can compile them as
 // three parallel translation units (dkt_stereo_amd/build.py: -DCONV_TU_PASSES=1|2|3; =0 holds the ABI
 // and the weight packer).  Compiled without the macro this file is one complete translation unit.
-int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st);
-int conv2d_launch_p2(const ConvArgs &a, int B, int KH, int stride, hipStream_t st);
-int conv2d_launch_p3(const ConvArgs &a, int B, int KH, int stride, hipStream_t st);
+int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec);
+int conv2d_launch_p2(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec);
+int conv2d_launch_p3(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec);
 
 template <int PASSES>
-static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) {
+static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) {
     if (stride == 2) {
+        if (sec) return DKT_E_UNSUPPORTED;
         if (KH == 3) return launch_conv_stride2<3, PASSES>(a, B, st);
         return launch_conv_stride2<1, PASSES>(a, B, st);
     }
-    if (KH == 3) return launch_conv_shape<3, PASSES>(a, B, st);
-    return launch_conv_shape<1, PASSES>(a, B, st);
+    if (KH == 3) return launch_conv_shape<3, PASSES>(a, B, st, sec);
+    return launch_conv_shape<1, PASSES>(a, B, st, sec);
 }
 #if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 1
-int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) { return conv2d_launch_passes<1>(a, B, KH, stride, st); }
+int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) { return conv2d_launch_passes<1>(a, B, KH, stride, st, sec); }
 #endif
 #if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 2
-int conv2d_launch_p2(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) { return conv2d_launch_passes<2>(a, B, KH, stride, st); }
+int conv2d_launch_p2(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) { return conv2d_launch_passes<2>(a, B, KH, stride, st, sec); }
 #endif
 #if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 3
-int conv2d_launch_p3(const ConvArgs &a, int B, int KH, int stride, hipStream_t st) { return conv2d_launch_passes<3>(a, B, KH, stride, st); }
+int conv2d_launch_p3(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) { return conv2d_launch_passes<3>(a, B, KH, stride, st, sec); }
 #endif
 
 #if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 0
@@ -702,18 +740,18 @@ struct ConvEpilogue {
     long out2_bs;
 };
 
-static int conv2d_f16s_impl(const float *const *src, const int *src_channels, const long *src_bstride,
-                            int nsrc, const void *w_hi, const void *w_lo, const float *bias,
-                            float out_scale, float in_scale, float *out, long out_bstride,
-                            int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
-                            const ConvEpilogue *epi, int device, void *stream, int stride = 1) {
+// validates one convolution's parameters and fills its kernel argument block
+static int conv_fill(ConvArgs &a, const float *const *src, const int *src_channels, const long *src_bstride,
+                     int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                     float out_scale, float in_scale, float *out, long out_bstride,
+                     int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
+                     const ConvEpilogue *epi, int stride) {
     if (!src || !src_channels || !src_bstride || !w_hi || !w_lo || !out) return DKT_E_NULL;
     if (stride != 1 && (stride != 2 || epi)) return DKT_E_UNSUPPORTED;
     if (nsrc < 1 || nsrc > CONV_MAX_SRC || B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || B > 65535) return DKT_E_SHAPE;
     if (KH != KW || (KH != 1 && KH != 3)) return DKT_E_UNSUPPORTED;
     if (passes < 1 || passes > 3) return DKT_E_UNSUPPORTED;
     if (!(in_scale > 0.0f) || !(out_scale > 0.0f)) return DKT_E_SHAPE;
-    ConvArgs a;
     for (int s = 0; s < CONV_MAX_SRC; ++s) {
         a.src[s] = s < nsrc ? src[s] : nullptr;
         a.src_bs[s] = s < nsrc ? src_bstride[s] : 0;
@@ -735,6 +773,7 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
     a.CoutPad = conv_cout_pad(Cout);
     a.nch16 = conv_padded_channels(src_channels, nsrc) / 16;
     a.tiles_w = (a.Wo + 31) / 32;
+    a.tiles_xy = a.n_co = a.total_tiles = 0;       // set by launch_conv (they depend on the tile shape)
     a.relu = relu ? 1 : 0;
     a.epi = 0;
     a.e_c0 = a.e_c1 = a.e_h = nullptr;
@@ -747,11 +786,58 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
         a.e_c0_bs = epi->c0_bs; a.e_c1_bs = epi->c1_bs; a.e_h_bs = epi->h_bs;
         a.out2 = epi->out2; a.out2_bs = epi->out2_bs;
     }
+    return DKT_OK;
+}
+
+static int conv_dispatch(const ConvArgs &a, int B, int KH, int stride, int passes, hipStream_t st, const ConvSecond *sec) {
+    if (passes == 3) return conv2d_launch_p3(a, B, KH, stride, st, sec);
+    if (passes == 2) return conv2d_launch_p2(a, B, KH, stride, st, sec);
+    return conv2d_launch_p1(a, B, KH, stride, st, sec);
+}
+
+static int conv2d_f16s_impl(const float *const *src, const int *src_channels, const long *src_bstride,
+                            int nsrc, const void *w_hi, const void *w_lo, const float *bias,
+                            float out_scale, float in_scale, float *out, long out_bstride,
+                            int B, int H, int W, int Cout, int KH, int KW, int relu, int passes,
+                            const ConvEpilogue *epi, int device, void *stream, int stride = 1) {
+    ConvArgs a;
+    const int rc = conv_fill(a, src, src_channels, src_bstride, nsrc, w_hi, w_lo, bias, out_scale, in_scale, out,
+                             out_bstride, B, H, W, Cout, KH, KW, relu, passes, epi, stride);
+    if (rc != DKT_OK) return rc;
     DKT_ENTER(device);
-    hipStream_t st = (hipStream_t)stream;
-    if (passes == 3) return conv2d_launch_p3(a, B, KH, stride, st);
-    if (passes == 2) return conv2d_launch_p2(a, B, KH, stride, st);
-    return conv2d_launch_p1(a, B, KH, stride, st);
+    return conv_dispatch(a, B, KH, stride, passes, (hipStream_t)stream, nullptr);
+}
+
+// ---- two convolutions in one launch (descriptor form) ----
+static int conv_fill_desc(ConvArgs &a, const dkt_conv_desc *d, int passes) {
+    if (!d) return DKT_E_NULL;
+    ConvEpilogue e = {d->epilogue, d->e0, d->e1, d->h, d->e0_bstride, d->e1_bstride, d->h_bstride, d->out2, d->out2_bstride};
+    if (d->epilogue < 0 || d->epilogue > 2) return DKT_E_UNSUPPORTED;
+    if (d->epilogue == 1) {
+        if (!d->e0 || !d->e1 || !d->h || !d->out2) return DKT_E_NULL;
+        if (d->Cout % 128 != 0) return DKT_E_UNSUPPORTED;          // Ch multiple of 64: z and r never share a wave
+    } else if (d->epilogue == 2) {
+        if (!d->e0 || !d->e1 || !d->h) return DKT_E_NULL;
+    }
+    return conv_fill(a, d->src, d->src_channels, d->src_bstride, d->nsrc, d->w_hi, d->w_lo, d->bias, d->out_scale,
+                     d->in_scale, d->out, d->out_bstride, d->B, d->H, d->W, d->Cout, d->KH, d->KW, d->relu, passes,
+                     d->epilogue ? &e : nullptr, 1);
+}
+
+static int conv_width_class(int Cout) { return Cout <= 32 ? 0 : Cout <= 64 ? 1 : Cout <= 128 ? 2 : 3; }
+
+extern "C" int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc *p1, int passes, int device, void *stream) {
+    ConvArgs a;
+    ConvSecond sec;
+    int rc = conv_fill_desc(a, p0, passes);
+    if (rc != DKT_OK) return rc;
+    rc = conv_fill_desc(sec.a, p1, passes);
+    if (rc != DKT_OK) return rc;
+    sec.B = p1->B;
+    // both problems run one kernel instantiation: same filter size and the same output-width class
+    if (p0->KH != p1->KH || conv_width_class(p0->Cout) != conv_width_class(p1->Cout)) return DKT_E_UNSUPPORTED;
+    DKT_ENTER(device);
+    return conv_dispatch(a, p0->B, p0->KH, 1, passes, (hipStream_t)stream, &sec);
 }
 
 extern "C" int dkt_conv2d_f16s(const float *const *src, const int *src_channels, const long *src_bstride,

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(DirectArgs a) {
             const int ow = w0 + PX * tx + p;
             if (ow >= a.W) continue;
             float v = acc[p][o] + bias;
-            if (a.relu) v = fmaxf(v, 0.0f);
+            if (a.relu) v = dkt_relu(v);
             yr[ow] = v;
         }
     }

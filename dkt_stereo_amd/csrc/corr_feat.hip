@@ -1,0 +1,285 @@
+// corr_feat.hip -- correlation lookup fused with the motion encoder's first layer.
+//
+// Reference: every GRU iteration runs  corr = corr_fn(coords1)  (core/corr.py:127-146, a
+// (B, L*K, H, W) tensor: 8.3 MB at 1/4 KITTI) and then  cor = relu(convc1(corr))
+// (core/update.py:72,79: a 1x1 convolution L*K -> 64).  As two kernels that is one dependent
+// coords -> taps -> store round trip on 3.5 waves per SIMD followed by a launch whose whole input
+// is the tensor just written.  Here one wave owns a 32-pixel segment of an image row:
+//   1. samples all L levels of the SKEWED pyramid (corr1d_skew.hip; same taps, same blend as
+//      dkt_corr1d_lookup_skew: the sampled values are bit-identical -- `tap` exposes them);
+//      the two half-waves take alternate levels of the same 32 pixels, values stay in registers;
+//   2. multiplies them by the (Cout x L*K) weight matrix on the matrix cores with the EXACT fp32
+//      MFMA (v_mfma_f32_32x32x2_f32: an fp32 fma chain, no operand rounding): A = weights, B =
+//      samples; with the levels split over the half-waves a lane's sample IS its B-fragment entry;
+//   3. adds the bias, applies ReLU and stores (Cout, 32 px) in 128-byte NCHW rows.
+// HBM traffic per pixel: L*(K+1)*4 B of pyramid + 4 B of coordinate read, Cout*4 B written; the
+// lookup tensor never exists.
+#include "dkt_common.h"
+#include <type_traits>
+
+typedef float cf_f32x16 __attribute__((ext_vector_type(16)));
+
+struct CorrFeatArgs {
+    DktPtrs skew;
+    const float *coords_x;
+    long coords_bstride;
+    const float *w;          // (L*K, Cout): the layer's weight TRANSPOSED (k-major: lanes along co are contiguous)
+    const float *bias;       // (Cout) or null
+    float *out;              // (B, Cout, H, W1)
+    long out_bstride;
+    float *tap;              // optional (B, L*K, H, W1): the sampled correlation values
+    long tap_bstride;
+    long HW;
+    int H, W1, W2, pitch, nseg, Cout, relu;
+    float inv_wm1[DKT_MAX_LEVELS];
+};
+
+__device__ __forceinline__ int cf_clamp_idx(float fl, int W) {
+    return (int)fminf(fmaxf(fl, -2.0f), (float)W + 1.0f);
+}
+
+// the sampler arithmetic of corr1d_skew.hip (skw_tap): reciprocal form of the reference's division,
+// bit-identical to dkt_tap
+__device__ __forceinline__ DktTap cf_tap(float x, float wm1, float inv, float half_wm1) {
+    const float a2 = __fmul_rn(2.0f, x);
+    float q = __fmul_rn(a2, inv);
+    q = __fmaf_rn(__fmaf_rn(-wm1, q, a2), inv, q);
+    q = __fmaf_rn(__fmaf_rn(-wm1, q, a2), inv, q);
+    const float xg = __fsub_rn(q, 1.0f);
+    const float ix = __fmul_rn(__fadd_rn(xg, 1.0f), half_wm1);
+    DktTap t;
+    t.fl = floorf(ix);
+    t.w = __fsub_rn(ix, t.fl);
+    t.e = __fsub_rn(1.0f, t.w);
+    return t;
+}
+
+// One wave = one 32-pixel segment of one image row.  Lane l: pixel l & 31; the two half-waves split the
+// LEVELS: half g = l >> 5 samples levels g, g + 2, ... (NV = ceil(L/2) * K values per lane).  MFMA step s
+// multiplies the pair (half 0's s-th value, half 1's s-th value): that IS the B fragment layout of
+// v_mfma_f32_32x32x2_f32 (lane l holds B[k = l >> 5][n = l & 31]) -- no data movement between lanes;
+// the A fragment pairs the matching weight columns.  Twice the waves and half the dependent chain of
+// a 64-pixel-per-wave form (the kernel is latency-bound: 1 800 waves for 1 024 SIMDs at 1/4 KITTI).
+// Block = 4 waves; grid.y = batch.  MC = ceil(Cout / 32) accumulator row blocks.
+template <int L, int R, int MC>
+__global__ __launch_bounds__(256) void corr_feat_kernel(CorrFeatArgs a) {
+    constexpr int K = 2 * R + 1;
+    constexpr int NK = L * K;
+    constexpr int LH = (L + 1) / 2;           // levels per half-wave
+    constexpr int NV = LH * K;                // values per lane = MFMA steps
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, g = lane >> 5;
+    const long gw = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const long hrow = gw / a.nseg;
+    if (hrow >= a.H) return;                  // wave-uniform
+    const int seg0 = (int)(gw - hrow * a.nseg) * 32;
+    const int w1 = seg0 + li;
+    const bool live = w1 < a.W1;
+    const int w1c = live ? w1 : a.W1 - 1;     // surplus lanes shadow the last pixel (their results are dropped)
+    const int b = blockIdx.y;
+    const long p = hrow * a.W1 + w1c;
+    const float cx = a.coords_x[(size_t)b * a.coords_bstride + p];
+
+    // ---- weights (k-major: wt[k][co]): A fragment of step s, row block m = W[co = 32m + li][k(g, s)]
+    float A[MC][NV];
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        const int lv = g + 2 * (s / K);
+        const int k = lv * K + (s % K);
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+            const int co = 32 * m + li;
+            const bool ok = lv < L && co < a.Cout;
+            const float wv = a.w[(long)(ok ? k : 0) * a.Cout + (ok ? co : 0)];
+            A[m][s] = ok ? wv : 0.0f;
+        }
+    }
+
+    // biases of this lane's output rows, fetched as one batch (clamped index, no per-element branch)
+    float bv[MC][16];
+#pragma unroll
+    for (int m = 0; m < MC; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[m][r] = 0.0f;
+    if (a.bias) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * g;
+                bv[m][r] = a.bias[co < a.Cout ? co : a.Cout - 1];
+            }
+    }
+
+    // ---- the lookup: v[j*K + k] = sample k of level g + 2j for this lane's pixel.  All window loads are
+    // unconditional (clamped address, zeroed by a select afterwards): the LH*(K+1) loads of a lane are
+    // in flight together.  Same taps and blend as corr1d_lookup_skew_kernel -> bit-identical samples.
+    float v[NV];
+    float win[LH][K + 1];
+    DktTap taps[LH][K];
+    int i0[LH];
+    bool odd = false;                         // some tap of this lane is not at i0 + k (only for non-finite x)
+    auto sample_level = [&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        // level of this half-wave: g + 2j (compile-time candidates selected per half: a lane-indexed
+        // kernel-argument array would cost a dependent memory load); the padding slot of an odd L
+        // samples level L-1 again and is multiplied by zero weights
+        constexpr int lvA = 2 * j < L ? 2 * j : L - 1, lvB = 2 * j + 1 < L ? 2 * j + 1 : L - 1;
+        const int lv = g ? lvB : lvA;
+        const int wi = a.W2 >> lv;
+        const int qm = (w1c >> lv) % wi;
+        const float *lvl = g ? a.skew.p[lvB] : a.skew.p[lvA];
+        const float *base = lvl + (((long)b * a.H + hrow) * wi) * (long)a.pitch + w1c;
+        const float xc = __fdiv_rn(cx, (float)(1 << lv));
+        const float wm1 = (float)(wi - 1);
+        const float hwm1 = __fdiv_rn(wm1, 2.0f);
+        const float inv = g ? a.inv_wm1[lvB] : a.inv_wm1[lvA];
+        // (levels of width 1 -- division by W-1 = 0 in the reference -- are refused by the host wrapper:
+        // a branch here would split the block and serialise the two levels' loads)
+#pragma unroll
+        for (int k = 0; k < K; ++k) taps[j][k] = cf_tap(__fadd_rn((float)(k - R), xc), wm1, inv, hwm1);
+        i0[j] = cf_clamp_idx(taps[j][0].fl, wi);
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            const int c = i0[j] + t;
+            const bool in = c >= 0 && c < wi;
+            int sidx = (in ? c : 0) - qm;
+            if (sidx < 0) sidx += wi;
+            const float x = base[(long)sidx * a.pitch];
+            win[j][t] = in ? x : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) odd |= cf_clamp_idx(taps[j][k].fl, wi) != i0[j] + k;
+    };
+    sample_level(std::integral_constant<int, 0>{});
+    if constexpr (LH > 1) sample_level(std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int j = 0; j < LH; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[j * K + k] = dkt_blend(win[j][k], win[j][k + 1], taps[j][k]);
+    if (__any(odd)) {                         // rare: re-sample the irregular taps one by one
+        auto resample = [&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            constexpr int lvA = 2 * j < L ? 2 * j : L - 1, lvB = 2 * j + 1 < L ? 2 * j + 1 : L - 1;
+            const int lv = g ? lvB : lvA;
+            const int wi = a.W2 >> lv;
+            const int qm = (w1c >> lv) % wi;
+            const float *base = (g ? a.skew.p[lvB] : a.skew.p[lvA]) + (((long)b * a.H + hrow) * wi) * (long)a.pitch + w1c;
+            auto at = [&](int c) -> float {
+                if (c < 0 || c >= wi) return 0.0f;
+                int sidx = c - qm;
+                if (sidx < 0) sidx += wi;
+                return base[(long)sidx * a.pitch];
+            };
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int ik = cf_clamp_idx(taps[j][k].fl, wi);
+                if (ik != i0[j] + k) v[j * K + k] = dkt_blend(at(ik), at(ik + 1), taps[j][k]);
+            }
+        };
+        resample(std::integral_constant<int, 0>{});
+        if constexpr (LH > 1) resample(std::integral_constant<int, 1>{});
+    }
+    if (a.tap && live) {
+        float *t = a.tap + (size_t)b * a.tap_bstride + p;
+#pragma unroll
+        for (int j = 0; j < LH; ++j)
+            if (g + 2 * j < L) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) t[(size_t)((g + 2 * j) * K + k) * a.HW] = v[j * K + k];
+            }
+    }
+
+    // ---- 1x1 convolution on the exact-fp32 matrix pipe: D[co][px] += W[co][k] * v[k][px]
+    cf_f32x16 acc[MC];
+#pragma unroll
+    for (int m = 0; m < MC; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[m][r] = 0.0f;
+            asm volatile("" ::"v"(bv[m][r]));      // biases resident before the epilogue (no load per store there)
+        }
+#pragma unroll
+    for (int s = 0; s < NV; ++s)
+#pragma unroll
+        for (int m = 0; m < MC; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m][s], v[s], acc[m], 0, 0, 0);
+
+    // ---- epilogue: C/D map col = l & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    float *ob = a.out + (size_t)b * a.out_bstride + hrow * a.W1 + w1c;
+    const bool full = 32 * MC <= a.Cout && seg0 + 32 <= a.W1;      // wave-uniform: no guards needed
+    if (full) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float y = __fadd_rn(acc[m][r], bv[m][r]);
+                if (a.relu) y = dkt_relu(y);
+                ob[(size_t)co * a.HW] = y;
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MC; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float y = __fadd_rn(acc[m][r], bv[m][r]);
+                if (a.relu) y = dkt_relu(y);
+                if (co < a.Cout && live) ob[(size_t)co * a.HW] = y;
+            }
+    }
+}
+
+template <int L, int R>
+static int cf_launch(const CorrFeatArgs &a, int B, hipStream_t st) {
+    const long waves = (long)a.H * a.nseg;
+    dim3 grid((unsigned)((waves + 3) / 4), (unsigned)B);
+    if (a.Cout <= 32) hipLaunchKernelGGL((corr_feat_kernel<L, R, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((corr_feat_kernel<L, R, 2>), grid, dim3(256), 0, st, a);
+    return dkt_launch_status();
+}
+
+extern "C" int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *coords_x, long coords_bstride,
+                                         const float *weight, const float *bias, float *out, long out_bstride,
+                                         float *tap, long tap_bstride,
+                                         int B, int H, int W1, int W2, int L, int r, int Cout, int relu,
+                                         int device, void *stream) {
+    if (!skew || !coords_x || !weight || !out) return DKT_E_NULL;
+    if (B <= 0 || H <= 0 || W1 <= 0 || W2 <= 0 || B > 65535 || Cout <= 0) return DKT_E_SHAPE;
+    if (L < 1 || L > DKT_MAX_LEVELS || (W2 >> (L - 1)) == 0) return DKT_E_LEVELS;
+    if (r < 0 || r > DKT_MAX_RADIUS) return DKT_E_RADIUS;
+    if (Cout > 64 || !((L == 4 || L == 2 || L == 3) && (r == 4 || r == 3))) return DKT_E_UNSUPPORTED;
+    if ((W2 >> (L - 1)) < 2) return DKT_E_UNSUPPORTED;     // a level of width 1: the general lookup handles its inf/NaN
+    CorrFeatArgs a;
+    for (int i = 0; i < DKT_MAX_LEVELS; ++i) {
+        a.skew.p[i] = i < L ? skew[i] : nullptr;
+        if (i < L && !skew[i]) return DKT_E_NULL;
+        const int wi = i < L ? (W2 >> i) : 0;
+        a.inv_wm1[i] = wi > 1 ? (float)(1.0 / (double)(wi - 1)) : 0.0f;
+    }
+    a.coords_x = coords_x;
+    a.coords_bstride = coords_bstride;
+    a.w = weight;
+    a.bias = bias;
+    a.out = out;
+    a.out_bstride = out_bstride;
+    a.tap = tap;
+    a.tap_bstride = tap_bstride;
+    a.HW = (long)H * W1;
+    a.H = H; a.W1 = W1; a.W2 = W2;
+    a.pitch = (W1 + 31) & ~31;                 // dkt_corr1d_skew_pitch
+    a.nseg = (W1 + 31) / 32;
+    a.Cout = Cout;
+    a.relu = relu ? 1 : 0;
+    DKT_ENTER(device);
+    hipStream_t st = (hipStream_t)stream;
+    if (r == 4) {
+        if (L == 4) return cf_launch<4, 4>(a, B, st);
+        if (L == 3) return cf_launch<3, 4>(a, B, st);
+        return cf_launch<2, 4>(a, B, st);
+    }
+    if (L == 4) return cf_launch<4, 3>(a, B, st);
+    if (L == 3) return cf_launch<3, 3>(a, B, st);
+    return cf_launch<2, 3>(a, B, st);
+}

@@ -90,3 +90,9 @@ __device__ __forceinline__ DktTap dkt_tap_rcp(float x, float wm1, float inv, flo
 __device__ __forceinline__ float dkt_blend(float v0, float v1, const DktTap &t) {
     return __fmaf_rn(v1, t.w, __fmul_rn(v0, t.e));
 }
+
+// ReLU that propagates NaN like torch.relu (fmaxf(NaN, 0) returns 0 and would turn a diverged
+// activation into a plausible-looking zero).
+__device__ __forceinline__ float dkt_relu(float v) {
+    return v < 0.0f ? 0.0f : v;
+}

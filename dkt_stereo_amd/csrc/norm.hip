@@ -74,14 +74,14 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float *__rest
             v.x = (v.x - mean) * invstd; v.y = (v.y - mean) * invstd;
             v.z = (v.z - mean) * invstd; v.w = (v.w - mean) * invstd;
             if (relu) {
-                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+                v.x = dkt_relu(v.x); v.y = dkt_relu(v.y); v.z = dkt_relu(v.z); v.w = dkt_relu(v.w);
             }
             *(float4 *)(q + i) = v;
         }
     } else {
         for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)blocks_per_plane * 256) {
             float v = (p[i] - mean) * invstd;
-            q[i] = relu ? fmaxf(v, 0.0f) : v;
+            q[i] = relu ? dkt_relu(v) : v;
         }
     }
 }
@@ -147,15 +147,15 @@ __global__ __launch_bounds__(256) void instnorm_add_relu_kernel(const float *__r
         for (long i = blockIdx.x * 1024L + 4L * threadIdx.x; i + 3 < HW; i += stride) {
             const float4 u = *(const float4 *)(pa + i);
             float4 v = *(const float4 *)(pc + i);
-            v.x = fmaxf(u.x + fmaxf((v.x - mean) * invstd, 0.0f), 0.0f);
-            v.y = fmaxf(u.y + fmaxf((v.y - mean) * invstd, 0.0f), 0.0f);
-            v.z = fmaxf(u.z + fmaxf((v.z - mean) * invstd, 0.0f), 0.0f);
-            v.w = fmaxf(u.w + fmaxf((v.w - mean) * invstd, 0.0f), 0.0f);
+            v.x = dkt_relu(u.x + dkt_relu((v.x - mean) * invstd));
+            v.y = dkt_relu(u.y + dkt_relu((v.y - mean) * invstd));
+            v.z = dkt_relu(u.z + dkt_relu((v.z - mean) * invstd));
+            v.w = dkt_relu(u.w + dkt_relu((v.w - mean) * invstd));
             *(float4 *)(q + i) = v;
         }
     } else {
         for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)blocks_per_plane * 256)
-            q[i] = fmaxf(pa[i] + fmaxf((pc[i] - mean) * invstd, 0.0f), 0.0f);
+            q[i] = dkt_relu(pa[i] + dkt_relu((pc[i] - mean) * invstd));
     }
 }
 
@@ -175,12 +175,12 @@ __global__ __launch_bounds__(256) void add_relu_kernel(const float *__restrict__
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 u = ((const float4 *)a)[i], v = ((const float4 *)b)[i];
         float4 o;
-        o.x = fmaxf(u.x + v.x, 0.0f); o.y = fmaxf(u.y + v.y, 0.0f);
-        o.z = fmaxf(u.z + v.z, 0.0f); o.w = fmaxf(u.w + v.w, 0.0f);
+        o.x = dkt_relu(u.x + v.x); o.y = dkt_relu(u.y + v.y);
+        o.z = dkt_relu(u.z + v.z); o.w = dkt_relu(u.w + v.w);
         ((float4 *)y)[i] = o;
     }
     for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        y[i] = fmaxf(a[i] + b[i], 0.0f);
+        y[i] = dkt_relu(a[i] + b[i]);
 }
 
 extern "C" int dkt_add_relu(const float *a, const float *b, float *y, long n, int device, void *stream) {

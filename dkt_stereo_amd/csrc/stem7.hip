@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void conv2d_stem7_kernel(Stem7Args a) {
             const int co = co0 + m * 32 + 4 * kg + (r & 3) + 8 * (r >> 2);
             if (co >= a.Cout) continue;
             float v = acc[m][r] * a.out_scale + (a.bias ? a.bias[co] : 0.0f);
-            if (a.relu) v = fmaxf(v, 0.0f);
+            if (a.relu) v = dkt_relu(v);
             yo[(long)co * HW] = v;
         }
 }

@@ -18,7 +18,12 @@ import weakref
 import torch
 
 from . import conv as _conv
-from .update import FUSE_GATES, _side_stream, capture_graph, harness
+import os
+
+from .update import FUSE_GATES, _side_stream, capture_graph, harness, interp, pool2x
+
+#: the coarsest GRU of the next iteration shares the finest GRU's two launches (dkt_conv2d_f16s_pair)
+PAIR_GRUS = os.environ.get("DKT_PAIR_GRUS", "1") != "0"
 
 
 def _plain(update_block, geo_fn, disp, coords, net_list, inp_list, iters):
@@ -52,12 +57,21 @@ def _body(ub, st, need_mask, last):
     side = _side_stream(dev)
     nets = list(st.net)
     done_mid = torch.cuda.Event()
-    with harness(inplace_state=True, side_stream=False, before_fine=lambda: main.wait_event(done_mid)):
+    up_mid, pool_mid = [], []
+    pair = PAIR_GRUS and not last
+    with harness(inplace_state=True, side_stream=False, before_fine=lambda: main.wait_event(done_mid),
+                 fine_interp=lambda: up_mid[0], pair_coarse=pair, coarse_pool=lambda: pool_mid[0]):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ub(nets, st.inp, iter04=False, iter08=True, iter16=False, update=False)        # mid GRU (i)
+            up_mid.append(interp(nets[1], nets[0]))      # the finest GRU's up-sampled operand, off the critical path
+            if pair:
+                pool_mid.append(pool2x(nets[1]))         # the coarsest GRU (i+1) shares the finest GRU's launches
+            if not torch.cuda.is_current_stream_capturing():
+                for t in up_mid + pool_mid:
+                    t.record_stream(main)
             done_mid.record(side)
-            if not last:
+            if not last and not pair:
                 ub(nets, st.inp, iter04=False, iter08=False, iter16=True, update=False)    # coarse GRU (i+1)
         geo_feat = st.geo_fn(st.disp, st.coords)
         nets, mask, delta = ub(nets, st.inp, geo_feat, st.disp, iter16=False, iter08=False, need_mask=need_mask)

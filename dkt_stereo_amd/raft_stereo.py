@@ -25,7 +25,7 @@ from . import _ffi
 from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
 from .extractor import BasicEncoder, MultiBasicEncoder
-from .update import FUSE_GATES, BasicMultiUpdateBlock, _side_stream, capture_graph, harness
+from .update import FUSE_GATES, BasicMultiUpdateBlock, _side_stream, capture_graph, harness, interp, pool2x
 from . import conv as _conv
 from .utils import coords_grid
 
@@ -132,13 +132,21 @@ class RAFTStereo(nn.Module):
 
     #: replay the GRU iteration from a captured HIP graph (one capture per input shape)
     use_hip_graph = True
+    #: hand the motion encoder a deferred lookup: lookup + convc1 run as one kernel
+    #: (dkt_corr1d_lookup_conv1x1); DKT_FUSE_LOOKUP=0 keeps the two launches
+    fuse_lookup = os.environ.get("DKT_FUSE_LOOKUP", "1") != "0"
+
+    def _lookup(self, corr_fn, coords1):
+        if self.fuse_lookup and hasattr(corr_fn, "deferred"):
+            return corr_fn.deferred(coords1)
+        return corr_fn(coords1)
 
     def _one_iteration(self, corr_fn, coords0, coords1, net_state, inp_list, need_mask):
         """One pass of raft_stereo.py:146-167 updating coords1 / net_state IN PLACE
         (static buffers, so the same code can be captured once and replayed)."""
         args = self.args
         n = args.n_gru_layers
-        corr = corr_fn(coords1)
+        corr = self._lookup(corr_fn, coords1)
         flow = coords1 - coords0
         nets = list(net_state)
         with harness(inplace_state=True):
@@ -165,6 +173,10 @@ class RAFTStereo(nn.Module):
     #: with the pipelined schedule: the motion encoder's flow branch on a third stream.  Opt-in
     #: (DKT_BRANCH_STREAMS=1): measured gain 0.3 ms per pair, not worth a third capture branch by default
     branch_streams = os.environ.get("DKT_BRANCH_STREAMS", "0") == "1"
+
+    #: with the pipelined schedule: gru32 of the next iteration shares the two launches of gru08
+    #: (dkt_conv2d_f16s_pair; DKT_PAIR_GRUS=0 keeps it as launches of its own on the side stream)
+    pair_grus = os.environ.get("DKT_PAIR_GRUS", "1") != "0"
 
     def _can_pipeline(self):
         a = self.args
@@ -194,15 +206,26 @@ class RAFTStereo(nn.Module):
         done16 = torch.cuda.Event()
         # the fork / join is done here (side_stream=False); the encoder runs on `main`, so its own
         # fork (branch_streams) is not nested inside another forked stream
+        up16, pool16 = [], []
+        pair = self.pair_grus and not last
         with harness(inplace_state=True, side_stream=False, branch_streams=self.branch_streams,
-                     before_fine=lambda: main.wait_event(done16)):
+                     before_fine=lambda: main.wait_event(done16), fine_interp=lambda: up16[0],
+                     pair_coarse=pair, coarse_pool=lambda: pool16[0]):
             side.wait_stream(main)                   # fork
             with torch.cuda.stream(side):
                 ub(nets, inp_list, iter32=False, iter16=True, iter08=False, update=False)      # gru16(i)
+                # gru08's up-sampled operand (core/update.py:127) is ready as soon as gru16 is: computed
+                # here, off the critical path (it cost 32 us per iteration in front of gru08)
+                up16.append(interp(nets[1], nets[0]))
+                if pair:
+                    pool16.append(pool2x(nets[1]))   # gru32(i+1)'s operand (core/update.py:119)
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in up16 + pool16:
+                        t.record_stream(main)
                 done16.record(side)
-                if not last:
+                if not last and not pair:
                     ub(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)  # gru32(i+1)
-            corr = corr_fn(coords1)
+            corr = self._lookup(corr_fn, coords1)
             flow = coords1 - coords0
             nets, up_mask, delta_flow = ub(nets, inp_list, corr, flow, iter32=False, iter16=False,
                                            need_mask=need_mask)
@@ -287,7 +310,7 @@ class RAFTStereo(nn.Module):
         net_list = list(net_list)
         up_mask = None
         for itr in range(iters):
-            corr = corr_fn(coords1)
+            corr = self._lookup(corr_fn, coords1)
             flow = coords1 - coords0
             if n == 3 and args.slow_fast_gru:
                 net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)

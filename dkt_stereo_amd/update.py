@@ -29,7 +29,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import _CACHE_LOCK, conv2d, conv2d_gate_out, conv2d_gate_zr, get_backend, hip_eligible
+from .conv import (_CACHE_LOCK, conv2d, conv2d_gate_out, conv2d_gate_out_pair, conv2d_gate_zr, conv2d_gate_zr_pair,
+                   get_backend, hip_eligible, pair_eligible)
 
 
 class _Harness(threading.local):
@@ -39,6 +40,9 @@ class _Harness(threading.local):
     inplace_state = False     # GRUs overwrite their hidden-state tensors instead of allocating new ones
     side_stream = None        # None: the module's default; False: the harness forks / joins itself
     before_fine = None        # hook called between the motion encoder and the finest GRU
+    fine_interp = None        # callable returning interp(net[1], net[0]) computed elsewhere (another stream)
+    pair_coarse = False       # run the coarsest GRU of the NEXT iteration in the launches of the finest GRU
+    coarse_pool = None        # callable returning pool2x(net[1]) for that paired coarsest GRU
     branch_streams = False    # motion encoder's flow branch on its own stream
 
 
@@ -177,6 +181,34 @@ class ConvGRU(nn.Module):
         return out
 
 
+def gru_pair(gru_a, args_a, gru_b, args_b):
+    """Two independent ConvGRU steps (core/update.py:23-32 twice) in TWO launches instead of four:
+    the z|r convolutions of both share one launch, so do the q convolutions (dkt_conv2d_f16s_pair).
+    args = (h, cz, cr, cq, x_list, out).  Meant for a large and a small image: the small one's tiles
+    fit in the tile-quantisation slack of the large one's launch.  Falls back to two plain calls
+    when the fused-gate path or the pairing does not apply.  Returns (h_a', h_b')."""
+    ok = (FUSE_GATES and hip_eligible(gru_a.convq) and hip_eligible(gru_b.convq)
+          and pair_eligible(gru_a.convq, gru_b.convq) and pair_eligible(gru_a.convz, gru_b.convz)
+          and args_a[0].shape[1] % 64 == 0 and args_b[0].shape[1] % 64 == 0
+          and args_a[0].shape[1] == args_b[0].shape[1])
+    if not ok:
+        ha, cza, cra, cqa, xa, oa = args_a
+        hb, czb, crb, cqb, xb, ob = args_b
+        return gru_a(ha, cza, cra, cqa, *xa, out=oa), gru_b(hb, czb, crb, cqb, *xb, out=ob)
+    prep = []
+    for gru, (h, cz, cr, cq, xs, out) in ((gru_a, args_a), (gru_b, args_b)):
+        _ffi.require_gpu(h, cz, cr, cq, *xs)
+        _ffi.require_no_grad(h, cz, cr, cq, *xs)
+        HW = h.shape[2] * h.shape[3]
+        if not _batch_dense(h, HW):
+            h = h.contiguous()
+        cz, cr, cq = [t if _batch_dense(t, HW) else t.contiguous() for t in (cz, cr, cq)]
+        prep.append((gru, h, cz, cr, cq, list(xs), out))
+    (za, rha), (zb, rhb) = conv2d_gate_zr_pair(*[([h, *xs], g._merged_zr(), cz, cr, h) for g, h, cz, cr, cq, xs, out in prep])
+    (ga, ha, _, _, cqa, xsa, oa), (gb, hb, _, _, cqb, xsb, ob) = prep
+    return tuple(conv2d_gate_out_pair(([rha, *xsa], ga.convq, cqa, za, ha, oa), ([rhb, *xsb], gb.convq, cqb, zb, hb, ob)))
+
+
 class BasicMotionEncoder(nn.Module):
     """core/update.py:64-85 (RAFT).  ``cor_planes = corr_levels * (2*corr_radius+1)``."""
 
@@ -198,6 +230,16 @@ class BasicMotionEncoder(nn.Module):
     # branch.  Only set when the encoder itself runs on the capture's origin stream (a fork nested
     # inside another forked stream crashed hipStreamEndCapture on ROCm 7.2).
 
+    def _cor1(self, corr):
+        """relu(convc1(corr)).  `corr` may be a corr.DeferredLookup (the loop harnesses pass one): lookup and
+        this 1x1 layer then run as ONE kernel on the exact-fp32 matrix pipe (dkt_corr1d_lookup_conv1x1)."""
+        if hasattr(corr, "materialize"):
+            out = corr.conv1x1(self.convc1, relu=True) if get_backend() != "miopen" else None
+            if out is not None:
+                return out
+            corr = corr.materialize()
+        return conv2d(corr, self.convc1, relu=True)
+
     def forward(self, flow, corr):
         if _HARNESS.branch_streams and flow.is_cuda:
             cur = torch.cuda.current_stream(flow.device)
@@ -206,10 +248,10 @@ class BasicMotionEncoder(nn.Module):
             with torch.cuda.stream(aux):
                 flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
                              getattr(self, self._branch[1]), relu=True)
-            cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
+            cor = conv2d(self._cor1(corr), self.convc2, relu=True)
             cur.wait_stream(aux)
         else:
-            cor = conv2d(conv2d(corr, self.convc1, relu=True), self.convc2, relu=True)
+            cor = conv2d(self._cor1(corr), self.convc2, relu=True)
             flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
                          getattr(self, self._branch[1]), relu=True)
         # [conv output (126/127 ch) | flow]: the convolution writes straight into the first
@@ -338,7 +380,16 @@ class BasicMultiUpdateBlock(nn.Module):
             if hs.before_fine is not None:
                 hs.before_fine()                # harness hook: wait for a coarse GRU running on another stream
             if n > 1:
-                net[0] = fine(net[0], *(inp[0]), mf, interp(net[1], net[0]), out=o(net[0]))
+                up = hs.fine_interp() if hs.fine_interp is not None else interp(net[1], net[0])
+                if hs.pair_coarse and n == 3:
+                    # pipelined harness: net[1] already holds this iteration's middle GRU, so the coarsest GRU
+                    # of the next iteration (inputs net[2], pool2x(net[1]); core/update.py:118-119) is ready
+                    # to run and independent of the finest GRU: both share their two launches
+                    net[0], net[2] = gru_pair(fine, (net[0], *(inp[0]), [mf, up], o(net[0])),
+                                              coarse, (net[2], *(inp[2]), [hs.coarse_pool() if hs.coarse_pool is not None
+                                                                            else pool2x(net[1])], o(net[2])))
+                else:
+                    net[0] = fine(net[0], *(inp[0]), mf, up, out=o(net[0]))
             else:
                 net[0] = fine(net[0], *(inp[0]), mf, out=o(net[0]))
         return net

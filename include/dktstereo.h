@@ -228,6 +228,21 @@ int dkt_gru_gate_out(const float *aq, const float *cq, long cq_bstride,
 
 /* ---- update-operator convolutions ------------------------------------------------ */
 
+/* Correlation lookup fused with the 1x1 convolution that consumes it: core/corr.py:127-146
+ * (CorrBlock1D.__call__) followed by relu(convc1(corr)) of BasicMotionEncoder (core/update.py:72,79).
+ * One launch; the (B, L*K, H, W1) lookup tensor is never written.  `skew` is the pyramid written by
+ * dkt_corr1d_skew; weight_t is convc1.weight viewed (Cout, L*K) and TRANSPOSED to (L*K, Cout), fp32,
+ * used as is: the product runs on the exact-fp32 matrix instruction (an fp32 fma chain over the taps).
+ *   out[b,co,h,w] = [relu]( bias[co] + sum_k weight[co,k] * lookup[b,k,h,w] )
+ * tap (optional, may be NULL): receives lookup[b,k,h,w] itself -- bit-identical to dkt_corr1d_lookup_skew.
+ * Supported: Cout <= 64, L in {2,3,4}, r in {3,4}; otherwise DKT_E_UNSUPPORTED (callers then run
+ * dkt_corr1d_lookup_skew + dkt_conv2d_f16s). */
+int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *coords_x, long coords_bstride,
+                              const float *weight_t, const float *bias, float *out, long out_bstride,
+                              float *tap, long tap_bstride,
+                              int B, int H, int W1, int W2, int L, int r, int Cout, int relu,
+                              int device, void *stream);
+
 /* nn.Conv2d (stride 1, "same" zero padding, 1x1 or 3x3) as used by ConvGRU,
  * BasicMotionEncoder, FlowHead/DispHead and the mask heads (core/update.py:9-10,
  * 19-21, 72-76, 111-113; meta_arch/igev_stereo/update.py same lines), evaluated
@@ -280,6 +295,34 @@ int dkt_conv2d_f16s_gate_out(const float *const *src, const int *src_channels, c
                              const float *cq, long cq_bstride, const float *z, long z_bstride,
                              const float *h, long h_bstride, float *hout, long hout_bstride,
                              int B, int H, int W, int Ch, int KH, int KW, int passes, int device, void *stream);
+
+/* Two independent convolutions of dkt_conv2d_f16s' kind (stride 1, optional ConvGRU gate epilogue) in ONE
+ * launch: the resident blocks of the persistent kernel are split between the two problems in proportion to
+ * their work.  Used to fold the coarsest GRU of iteration i+1 (36 tiles at 1/16 KITTI) into the launches of
+ * the finest GRU of iteration i (core/update.py:118-127; the two are independent), where it fits in the
+ * tile-quantisation slack.  Both problems must have the same KH and fall in the same output-width class
+ * (<= 32, <= 64, <= 128, wider), else DKT_E_UNSUPPORTED.
+ *   epilogue 0: out = out_scale*acc + bias [ReLU];  Cout = layer outputs
+ *   epilogue 1: merged z|r layer, Cout = 2*Ch: z -> out, r*h -> out2 (e0 = cz, e1 = cr)
+ *   epilogue 2: q layer, Cout = Ch: (1-z)*h + z*tanh(v + cq) -> out (e0 = cq, e1 = z; out may alias h) */
+typedef struct dkt_conv_desc {
+    const float *src[DKT_CONV_MAX_SRC];
+    long src_bstride[DKT_CONV_MAX_SRC];
+    int src_channels[DKT_CONV_MAX_SRC];
+    int nsrc;
+    const void *w_hi, *w_lo;
+    const float *bias;
+    float out_scale, in_scale;
+    float *out;
+    long out_bstride;
+    int B, H, W, Cout, KH, KW, relu;
+    int epilogue;
+    const float *e0; long e0_bstride;
+    const float *e1; long e1_bstride;
+    const float *h;  long h_bstride;
+    float *out2;     long out2_bstride;
+} dkt_conv_desc;
+int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc *p1, int passes, int device, void *stream);
 
 /* The 7x7 stems (Cin <= 4, stride 1, padding 3: core/update.py:75, igev_stereo/update.py:81,
  * core/extractor.py:136) on the fp16 matrix cores with split operands (stem7.hip): K laid out

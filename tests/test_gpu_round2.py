@@ -333,3 +333,97 @@ def test_two_threads_two_replicas_one_device():
         t.join()
     assert not err, err
     assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+
+
+# ---------------------------------------------------------------------------------
+# lookup fused with the motion encoder's 1x1 layer (dkt_corr1d_lookup_conv1x1)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(_cases.CORR_CASES))
+@pytest.mark.parametrize("cout,relu", [(64, True), (40, False), (7, True)])
+@torch.no_grad()
+def test_lookup_conv1x1_fused(name, cout, relu):
+    """The sampled values (debug tap) are BIT-IDENTICAL to the stand-alone lookup; the 1x1 product is an
+    fp32 fma chain on the matrix pipe: within fp32 round-off of an fp64 contraction of the same samples."""
+    from dkt_stereo_amd.corr import CorrBlock1D
+    c = _cases.CORR_CASES[name]
+    f1, f2, co = _cases.corr_inputs(c)
+    blk = CorrBlock1D(G(f1), G(f2), num_levels=c["L"], radius=c["r"])
+    nk = c["L"] * (2 * c["r"] + 1)
+    layer = torch.nn.Conv2d(nk, cout, 1).to(DEV)
+    res = blk.lookup_conv1x1(G(co), layer, relu=relu, tap=True)
+    if c["L"] not in (2, 3, 4) or c["r"] not in (3, 4):
+        assert res is None
+        return
+    out, tap = res
+    want_tap = blk(G(co))
+    assert torch.equal(tap, want_tap) or (torch.equal(torch.isnan(tap), torch.isnan(want_tap))
+                                          and torch.equal(torch.nan_to_num(tap), torch.nan_to_num(want_tap)))
+    ref = F.conv2d(want_tap.double(), layer.weight.double(), layer.bias.double())
+    ref = ref.clamp_min(0) if relu else ref
+    ok = torch.isfinite(ref)
+    scale = max(float(ref[ok].abs().max()), 1.0)
+    assert float((out.double() - ref)[ok].abs().max()) <= 2e-6 * scale
+    # the deferred object the harness hands to the motion encoder
+    d = blk.deferred(G(co))
+    assert torch.equal(d.materialize(), want_tap)
+    assert torch.equal(d.conv1x1(layer, relu=relu), out)
+
+
+@torch.no_grad()
+def test_lookup_conv1x1_full_size_and_unfused_path_agree(golden):
+    """cfg2 shapes: fused kernel vs lookup + convolution; the end-to-end result with fusion off."""
+    from dkt_stereo_amd.corr import CorrBlock1D
+    f1, f2 = _synth.fmap_pair(5, 1, 256, 184, 312)
+    co = _synth.coords(5, 1, 184, 312)
+    blk = CorrBlock1D(G(f1), G(f2), num_levels=4, radius=4)
+    layer = torch.nn.Conv2d(36, 64, 1).to(DEV)
+    out, tap = blk.lookup_conv1x1(G(co), layer, relu=True, tap=True)
+    want_tap = blk(G(co))
+    assert torch.equal(tap, want_tap)
+    ref = F.conv2d(want_tap.double(), layer.weight.double(), layer.bias.double()).clamp_min(0)
+    assert float((out.double() - ref).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1.0)
+    c = _cases.E2E_CASES["256x512_it8"]
+    i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+    model, _ = _raft()
+    g = golden("raft_e2e")
+    s = int(g["256x512_it8/stride"])
+    for fuse in (True, False):
+        model.fuse_lookup = fuse
+        model._graph_state = None
+        up = model(G(i1), G(i2), iters=c["iters"], test_mode=True)[1]
+        assert maxabs(up[:, :, ::s, ::s], g["256x512_it8/flow_up"]) <= 1e-3
+
+
+# ---------------------------------------------------------------------------------
+# two GRUs in shared launches (dkt_conv2d_f16s_pair)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("shapes", [((1, 184, 312), (1, 46, 78)), ((2, 20, 40), (2, 5, 10)), ((1, 33, 70), (3, 9, 17))])
+@torch.no_grad()
+def test_gru_pair_equals_two_separate_grus(shapes):
+    """The paired launch changes how tiles are distributed over blocks, not the arithmetic of any output
+    element: bit-identical to running the two ConvGRUs one after the other (core/update.py:23-32)."""
+    from dkt_stereo_amd.update import ConvGRU, gru_pair
+    (Ba, Ha, Wa), (Bb, Hb, Wb) = shapes
+    ga, gb = ConvGRU(128, 256).to(DEV), ConvGRU(128, 128).to(DEV)
+    R = lambda *s: torch.randn(*s, device=DEV)      # noqa: E731
+    args = []
+    for (B, H, W, nx) in ((Ba, Ha, Wa, 2), (Bb, Hb, Wb, 1)):
+        args.append((torch.tanh(R(B, 128, H, W)), R(B, 128, H, W), R(B, 128, H, W), R(B, 128, H, W),
+                     [R(B, 128, H, W) for _ in range(nx)], None))
+    want_a = ga(*args[0][:4], *args[0][4])
+    want_b = gb(*args[1][:4], *args[1][4])
+    got_a, got_b = gru_pair(ga, args[0], gb, args[1])
+    assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
+    # in place (what the loop harness does): the hidden state tensors are overwritten
+    ha, hb = args[0][0].clone(), args[1][0].clone()
+    ia, ib = gru_pair(ga, (ha, *args[0][1:5], ha), gb, (hb, *args[1][1:5], hb))
+    assert ia.data_ptr() == ha.data_ptr() and ib.data_ptr() == hb.data_ptr()
+    assert torch.equal(ha, want_a) and torch.equal(hb, want_b)
+
+
+@torch.no_grad()
+def test_pair_refuses_mismatched_problems():
+    from dkt_stereo_amd import _ffi, conv
+    la, lb = torch.nn.Conv2d(64, 256, 3, padding=1).to(DEV), torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV)
+    assert not conv.pair_eligible(la, lb)
+    assert conv.pair_eligible(la, torch.nn.Conv2d(32, 200, 3, padding=1).to(DEV))
