@@ -115,17 +115,21 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
     return v.u;
 }
 
+struct ConvArgsPair {
+    ConvArgs p[2];
+};
+
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
 template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) void conv2d_f16s_kernel(ConvArgs a0, ConvArgs a1, int nb0) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) void conv2d_f16s_kernel(ConvArgsPair ap, int nb0) {
     // Two independent convolutions may share one launch (dkt_conv2d_f16s_pair): blocks [0, nb0) stream
     // the tiles of problem 0, the others those of problem 1 -- a small layer (the coarsest GRU: 36
     // tiles) then rides in the tile-quantisation slack of a large one (the finest GRU: 460 tiles on
     // 256 resident blocks) instead of occupying the device for a launch of its own.  The selection
     // is block-uniform: every a.field below is a scalar load from the chosen argument block.
     const bool second = (int)blockIdx.x >= nb0;
-    const ConvArgs &a = second ? a1 : a0;
+    const ConvArgs &a = ap.p[second ? 1 : 0];      // uniform index into the kernel-argument segment: scalar loads
     const int blk_first = second ? nb0 : 0;
     const int blk_count = second ? (int)gridDim.x - nb0 : nb0;
     constexpr int HALO = KS / 2;
@@ -617,7 +621,10 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec 
     const long cap = slots[dev & 63];
     if (!sec) {
         const long nblk = persist && total > cap ? cap : total;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, a, a, (int)nblk);
+        ConvArgsPair ap;
+        ap.p[0] = a;
+        ap.p[1] = a;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, ap, (int)nblk);
         return dkt_launch_status();
     }
     // ---- two problems: resident blocks are split in proportion to the work (tiles x chunks)
@@ -636,7 +643,10 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec 
         if (nb0 > total) nb0 = total;
         if (nb0 < 1) nb0 = 1;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nb0 + nb1)), dim3(64 * WM * WN), lds, st, a, b, (int)nb0);
+    ConvArgsPair ap;
+    ap.p[0] = a;
+    ap.p[1] = b;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nb0 + nb1)), dim3(64 * WM * WN), lds, st, ap, (int)nb0);
     return dkt_launch_status();
 }
 
