@@ -169,6 +169,7 @@ def clear_weight_cache(module):
             m.__dict__.pop("_dkt_packed", None)
             m.__dict__.pop("_dkt_folded", None)
             m.__dict__.pop("_dkt_stem7", None)
+            m.__dict__.pop("_dkt_wt", None)
             if hasattr(m, "_zr_cache"):
                 m._zr_cache = None
 

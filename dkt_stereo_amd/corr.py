@@ -16,10 +16,13 @@ the reference's grid_sample / avg_pool2d / einsum chain.  Coordinates must be de
 reference's callers do (raft_stereo.py:152).  The other classes are inference only.
 """
 import os
+import threading
 
 import torch
 
 from . import _ffi
+
+_WT_LOCK = threading.Lock()
 
 
 def _build_pyramid(fmap1, fmap2, num_levels, divisor, out=None):
@@ -222,11 +225,14 @@ class CorrBlock1D:
             coords = coords.contiguous()
         cout = w.shape[0]
         # the kernel wants the weight k-major, (L*K, Cout); cached on the layer per device and version
+        # (under the lock: a thread that lost a creation race would otherwise free the tensor another
+        # thread's captured graph already points to)
         key = (w.data_ptr(), w._version)
-        hit = layer.__dict__.get("_dkt_wt", {}).get(str(w.device))
-        if hit is None or hit[0] != key:
-            hit = (key, w.detach().reshape(cout, -1).t().float().contiguous())
-            layer.__dict__.setdefault("_dkt_wt", {})[str(w.device)] = hit
+        with _WT_LOCK:
+            cache = layer.__dict__.setdefault("_dkt_wt", {})
+            hit = cache.get(str(w.device))
+            if hit is None or hit[0] != key:
+                hit = cache[str(w.device)] = (key, w.detach().reshape(cout, -1).t().float().contiguous())
         wm = hit[1]
         bias = layer.bias
         out = torch.empty((B, cout, H, W1), device=coords.device, dtype=torch.float32)

@@ -420,80 +420,6 @@ extern "C" int dkt_corr1d_lookup(const float *const *pyr, const float *coords_x,
 }
 
 // ---------------------------------------------------------------------------
-// On-the-fly lookup ("alt", core/corr.py:64-107): no volume; per (pixel, level,
-// tap) sample the pooled right feature map bilinearly in (x, y) exactly as
-// grid_sample does and dot with the left feature vector.  One thread per
-// (pixel, tap); lanes along w1 so f1 and the output are coalesced and the
-// right-map reads of neighbouring pixels share cache lines.
-// ---------------------------------------------------------------------------
-struct OtfArgs {
-    const float *f1;
-    DktPtrs f2;
-    const float *coords;
-    float *out;
-    int C, H, W1, W2, L, R;
-    float sqrtC;
-};
-
-__global__ __launch_bounds__(256) void corr1d_otf_kernel(OtfArgs a) {
-    const long HW = (long)a.H * a.W1;
-    const long p = blockIdx.x * 256L + threadIdx.x;
-    if (p >= HW) return;
-    const int K = 2 * a.R + 1;
-    const int lv = blockIdx.y / K, k = blockIdx.y % K;
-    const int b = blockIdx.z;
-    const int wi = a.W2 >> lv;
-    const float cx = a.coords[(size_t)b * 2 * HW + p];
-    const float cy = a.coords[(size_t)b * 2 * HW + HW + p];
-    const float wm1 = (float)(wi - 1), hm1 = (float)(a.H - 1);
-    DktTap tx = dkt_tap(__fadd_rn(__fdiv_rn(cx, (float)(1 << lv)), (float)(k - a.R)), wm1, __fdiv_rn(wm1, 2.0f));
-    DktTap ty = dkt_tap(cy, hm1, __fdiv_rn(hm1, 2.0f));
-    const int x0 = dkt_clamp_idx(tx.fl, wi), y0 = dkt_clamp_idx(ty.fl, a.H);
-    const bool x0ok = x0 >= 0 && x0 < wi, x1ok = x0 + 1 >= 0 && x0 + 1 < wi;
-    const bool y0ok = y0 >= 0 && y0 < a.H, y1ok = y0 + 1 >= 0 && y0 + 1 < a.H;
-    const float nw = __fmul_rn(ty.e, tx.e), ne = __fmul_rn(ty.e, tx.w);
-    const float sw = __fmul_rn(ty.w, tx.e), se = __fmul_rn(ty.w, tx.w);
-    const size_t cs2 = (size_t)a.H * wi;
-    const float *img = a.f2.p[lv] + (size_t)b * a.C * cs2;
-    const float *pf1 = a.f1 + (size_t)b * a.C * HW + p;
-    const long onw = (long)y0 * wi + x0;
-    float acc = 0.0f;
-    for (int c = 0; c < a.C; ++c) {
-        float vnw = (x0ok && y0ok) ? img[onw] : 0.0f;
-        float vne = (x1ok && y0ok) ? img[onw + 1] : 0.0f;
-        float vsw = (x0ok && y1ok) ? img[onw + wi] : 0.0f;
-        float vse = (x1ok && y1ok) ? img[onw + wi + 1] : 0.0f;
-        float s = __fmaf_rn(vse, se, __fmaf_rn(vsw, sw, __fmaf_rn(vne, ne, __fmul_rn(vnw, nw))));
-        acc = __fadd_rn(acc, __fmul_rn(s, pf1[0]));
-        img += cs2;
-        pf1 += HW;
-    }
-    a.out[((size_t)b * a.L * K + (size_t)lv * K + k) * HW + p] = __fdiv_rn(acc, a.sqrtC);
-}
-
-extern "C" int dkt_corr1d_lookup_otf(const float *f1, const float *const *f2pyr, const float *coords,
-                                     float *out, int B, int C, int H, int W1, int W2, int L, int r,
-                                     int device, void *stream) {
-    if (!f1 || !f2pyr || !coords || !out) return DKT_E_NULL;
-    if (B <= 0 || C <= 0 || H <= 0 || W1 <= 0 || W2 <= 0 || B > 65535) return DKT_E_SHAPE;
-    if (L < 1 || L > DKT_MAX_LEVELS || (W2 >> (L - 1)) == 0) return DKT_E_LEVELS;
-    if (r < 0 || r > DKT_MAX_RADIUS) return DKT_E_RADIUS;
-    OtfArgs a;
-    for (int i = 0; i < DKT_MAX_LEVELS; ++i) {
-        a.f2.p[i] = i < L ? f2pyr[i] : nullptr;
-        if (i < L && !f2pyr[i]) return DKT_E_NULL;
-    }
-    DKT_ENTER(device);
-    a.f1 = f1; a.coords = coords; a.out = out;
-    a.C = C; a.H = H; a.W1 = W1; a.W2 = W2; a.L = L; a.R = r;
-    a.sqrtC = sqrtf((float)C);
-    long HW = (long)H * W1;
-    dim3 grid((unsigned)((HW + 255) / 256), (unsigned)(L * (2 * r + 1)), (unsigned)B);
-    hipLaunchKernelGGL(corr1d_otf_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-    return dkt_launch_status();
-}
-
-// ---------------------------------------------------------------------------
 // L2 normalisation over channels (CorrBlock1D_Cosine prologue, corr.py:201-202)
 // torch: x / x.norm(dim=1, keepdim=True); norm = sqrt(sum x^2)
 // ---------------------------------------------------------------------------

@@ -427,3 +427,32 @@ def test_pair_refuses_mismatched_problems():
     la, lb = torch.nn.Conv2d(64, 256, 3, padding=1).to(DEV), torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV)
     assert not conv.pair_eligible(la, lb)
     assert conv.pair_eligible(la, torch.nn.Conv2d(32, 200, 3, padding=1).to(DEV))
+
+
+# ---------------------------------------------------------------------------------
+# on-the-fly lookup: LDS-staged window path and the general (gather) path
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["rows", "vertical_shift", "fractional_y", "wide_windows"])
+@torch.no_grad()
+def test_otf_lookup_paths(mode):
+    """PytorchAlternateCorrBlock1D (core/corr.py:64-107) against the oracle restatement of the reference on
+    coordinates that exercise both kernel paths: the pixel's own row with smooth disparity (staged window),
+    a vertical offset / fractional y (grid_sample's 4-tap arithmetic, general path), and windows spread over
+    more columns than the staged window holds (general path)."""
+    from oracle import torch_oracle as to
+    from dkt_stereo_amd.corr import PytorchAlternateCorrBlock1D
+    B, C, H, W = 2, 48, 6, 150
+    f1, f2 = _synth.fmap_pair(401, B, C, H, W)
+    co = _synth.coords(401, B, H, W, spread=8.0)
+    if mode == "vertical_shift":
+        co[:, 1] += 1.0
+    elif mode == "fractional_y":
+        co[:, 1] += _synth.uniform((B, H, W), -0.7, 0.7, 402, "dy")
+    elif mode == "wide_windows":
+        co = _synth.coords(403, B, H, W, spread=140.0)
+    got = PytorchAlternateCorrBlock1D(G(f1), G(f2), num_levels=3, radius=4)(G(co))
+    want = to.corr1d_lookup_alt(torch.from_numpy(f1), torch.from_numpy(f2), torch.from_numpy(co), 3, 4).numpy()
+    scale = max(float(np.abs(want).max()), 1.0)
+    d = maxabs(got, want)
+    print("otf %s: max|d| %.3e (scale %.2f)" % (mode, d, scale))
+    assert d <= 4e-6 * scale

@@ -44,7 +44,8 @@ def main():
     f1, f2 = R(B, 256, H, W), R(B, 256, H, W)
     blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
     xs = torch.arange(W, device=DEV, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
-    coords = torch.cat([xs - 20.0 - 3.0 * torch.rand(B, 1, H, W, device=DEV), torch.zeros(B, 1, H, W, device=DEV)], 1).contiguous()
+    ys = torch.arange(H, device=DEV, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
+    coords = torch.cat([xs - 20.0 - 3.0 * torch.rand(B, 1, H, W, device=DEV), ys], 1).contiguous()
     flow = R(B, 2, H, W)
     net = [torch.tanh(R(B, 128, H >> i, W >> i)) for i in range(3)]
     inp = [[R(B, 128, H >> i, W >> i) for _ in range(3)] for i in range(3)]
@@ -58,6 +59,9 @@ def main():
     T("lookup (skew)", lambda: blk(coords))
     T("convc1 1x1 36->64", lambda: conv2d(corr, enc.convc1, relu=True))
     T("lookup+convc1 fused", lambda: blk.lookup_conv1x1(coords, enc.convc1))
+    from dkt_stereo_amd.corr import PytorchAlternateCorrBlock1D
+    alt = PytorchAlternateCorrBlock1D(f1, f2, num_levels=4, radius=4)
+    T("lookup on the fly (alt)", lambda: alt(coords))
     c1 = conv2d(corr, enc.convc1, relu=True)
     T("convc2 64->64", lambda: conv2d(c1, enc.convc2, relu=True))
     T("convf1 7x7 2->64", lambda: conv2d(flow, enc.convf1, relu=True))
@@ -70,13 +74,16 @@ def main():
     T("interp 1/8->1/4", lambda: interp(net[1], net[0]))
     T("pool2x 1/4->1/8", lambda: pool2x(net[0]))
     T("gru08 (zr+q)", lambda: ub.gru08(net[0], *inp[0], mf, up))
+    from dkt_stereo_amd.update import gru_pair
+    pl = pool2x(net[1])
+    T("gru08 + gru32 paired", lambda: gru_pair(ub.gru08, (net[0], *inp[0], [mf, up], None), ub.gru32, (net[2], *inp[2], [pl], None)))
     T("gru16 (zr+q)", lambda: ub.gru16(net[1], *inp[1], pool2x(net[0]), interp(net[2], net[1])))
     T("gru32 (zr+q)", lambda: ub.gru32(net[2], *inp[2], pool2x(net[1])))
     T("flow_head conv1 128->256", lambda: conv2d(net[0], ub.flow_head.conv1, relu=True))
     y = conv2d(net[0], ub.flow_head.conv1, relu=True)
     T("flow_head conv2 256->2", lambda: conv2d(y, ub.flow_head.conv2))
     tot = sum(us for n, us in rows if n not in ("lookup (skew)", "convc1 1x1 36->64", "convc2 64->64", "convf1 7x7 2->64",
-                                                 "convf2 64->64", "enc.conv 128->126", "lookup+convc1 fused"))
+                                                 "convf2 64->64", "enc.conv 128->126", "lookup+convc1 fused", "lookup on the fly (alt)", "gru08 + gru32 paired"))
     print("sum of stand-alone stage times      %8.1f us" % tot)
     # the whole pipelined iteration as the harness runs it
     i1, i2 = _synth.image_pair(3, B, 736, 1248, 40)
