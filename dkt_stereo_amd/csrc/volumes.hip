@@ -7,6 +7,7 @@
 // are organised around full-width coalesced plane writes; the target row is
 // staged once in LDS so the D shifted re-reads never leave the CU.
 #include "dkt_common.h"
+#include <cstdlib>
 
 // One block per (b, g, h) row.  LDS: tgt[cpg][W].  Each thread owns pixels
 // w = tid, tid+256, ... and for each d forms the group mean
@@ -46,6 +47,98 @@ __global__ __launch_bounds__(256) void gwc_volume_kernel(const float *__restrict
                 out = __fdiv_rn(s, fcpg);
             }
             vrow[(size_t)d * HW + w] = out;
+        }
+    }
+}
+
+// Quad form (the default): a work item is (four consecutive disparities, four consecutive pixels) -> four
+// float4 stores.  Both the target and the reference row set of the group sit in LDS (target rows with `lpad`
+// floats of slack on the left so that w - d needs no clamp); per channel an item reads ONE aligned quad of
+// the reference and TWO aligned quads of the target (the 7 columns its 16 outputs touch) -- three 16-byte
+// LDS reads per 16 outputs where the one-pixel form issued one 4-byte read per output.  A thread walks the
+// row's D/4 * W/4 items with a stride of 256: every lane is busy whatever W is (the one-pixel form kept 61 %
+// of them busy at W = 312 and issued one scalar store per output), the footprint is ~60 registers (8 waves
+// per SIMD hide the LDS and store latency), and the sum stays the reference's: s = s + r_j * t_j over the group's channels in
+// ascending order, products rounded before they are added, mean by the same division.  Bit-identical.
+typedef float gwc_f2 __attribute__((ext_vector_type(2)));
+template <bool VEC>
+__global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__restrict__ ref,
+                                                              const float *__restrict__ tgt,
+                                                              float *__restrict__ vol, int C, int H, int W,
+                                                              int D, int G, long vol_bstride, int lpad) {
+    const int cpg = C / G;
+    const int h = blockIdx.x % H;
+    const int g = (blockIdx.x / H) % G;
+    const int b = blockIdx.x / (H * G);
+    const size_t HW = (size_t)H * W;
+    const size_t chan0 = ((size_t)b * C + (size_t)g * cpg) * HW + (size_t)h * W;
+    const int rpitch = (W + 7) & ~3;                                 // reference rows: 16-byte aligned quads
+    const int pitch = lpad + rpitch;
+    float *rlds = gwc_lds + cpg * pitch;
+    const int n_el = cpg * W;
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += 256 * 4) {          // both row sets -> LDS, 8 loads in flight
+        float v[4], u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            const int j = i / W, w = i - j * W;
+            v[k] = i < n_el ? tgt[chan0 + (size_t)j * HW + w] : 0.0f;
+            u[k] = i < n_el ? ref[chan0 + (size_t)j * HW + w] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            const int j = i / W, w = i - j * W;
+            if (i < n_el) {
+                gwc_lds[j * pitch + lpad + w] = v[k];
+                rlds[j * rpitch + w] = u[k];
+            }
+        }
+    }
+    __syncthreads();
+    const float fcpg = (float)cpg;
+    const bool pow2 = (cpg & (cpg - 1)) == 0;                        // such a mean divides exactly by multiplication
+    const float rcp = 1.0f / fcpg;
+    const int nq = (W + 3) / 4, ndq = (D + 3) / 4;
+    float *vrow = vol + (size_t)b * vol_bstride + (size_t)g * D * HW + (size_t)h * W;
+    for (int item = threadIdx.x; item < nq * ndq; item += 256) {
+        const int dq = item / nq, w = 4 * (item - dq * nq), d0 = 4 * dq;
+        // target columns (w + i) - (d0 + dd), i, dd in 0..3, span [w - d0 - 3, w - d0 + 3]: read as the two
+        // ALIGNED quads starting at w - d0 - 4 (w, d0, lpad multiples of 4) -> t8[0..7], column c at t8[c - (w-d0-4)]
+        const float *tp = gwc_lds + lpad + w - d0 - 4;               // >= gwc_lds: d0 + 4 <= lpad
+        const float *rp = rlds + w;
+        gwc_f2 s[4][2];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) s[dd][0] = s[dd][1] = gwc_f2{0.0f, 0.0f};
+#pragma unroll 4
+        for (int j = 0; j < cpg; ++j) {
+            const float4 rq = *(const float4 *)(rp + j * rpitch);    // (entries past W feed unstored outputs only)
+            const float4 ta = *(const float4 *)(tp + j * pitch), tb = *(const float4 *)(tp + j * pitch + 4);
+            const float t8[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+            const gwc_f2 r01{rq.x, rq.y}, r23{rq.z, rq.w};
+            // packed fp32: v_pk_mul_f32 then v_pk_add_f32 (never fused: the reference rounds the product first)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                s[dd][0] = s[dd][0] + r01 * gwc_f2{t8[4 - dd], t8[5 - dd]};
+                s[dd][1] = s[dd][1] + r23 * gwc_f2{t8[6 - dd], t8[7 - dd]};
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = d0 + dd;
+            if (d >= D) break;
+            const float sv[4] = {s[dd][0].x, s[dd][0].y, s[dd][1].x, s[dd][1].y};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (w + i >= d) ? (pow2 ? __fmul_rn(sv[i], rcp) : __fdiv_rn(sv[i], fcpg)) : 0.0f;
+            float *dst = vrow + (size_t)d * HW + w;
+            if (VEC && w + 3 < W) {
+                *(float4 *)dst = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (w + i < W) dst[i] = o[i];
+            }
         }
     }
 }
@@ -143,9 +236,22 @@ extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
         hipLaunchKernelGGL(gwc_volume_big_kernel,
                            dim3((unsigned)blocks, (unsigned)((D + GWC_BIG_DCHUNK - 1) / GWC_BIG_DCHUNK)), dim3(256), lds, (hipStream_t)stream,
                            ref, tgt, vol, C, H, W, D, G, vol_bstride);
-    else
-        hipLaunchKernelGGL(gwc_volume_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
-                           ref, tgt, vol, C, H, W, D, G, vol_bstride);
+    else {
+        // float4 plane stores need 16-byte aligned rows: W and the batch stride multiples of 4, aligned base
+        const bool vec = W % 4 == 0 && vol_bstride % 4 == 0 && ((uintptr_t)vol & 15) == 0;
+        static const bool legacy = [] { const char *e = getenv("DKT_GWC_LEGACY"); return e && atoi(e) != 0; }();
+        const int lpad = ((D + 3) & ~3) + 4;
+        const int rp = (W + 7) & ~3;
+        const size_t lds_q = (size_t)cpg * (lpad + 2 * rp) * sizeof(float);
+        dim3 grid((unsigned)blocks), blk(256);
+        hipStream_t st = (hipStream_t)stream;
+        if (legacy || lds_q > 64 * 1024)
+            hipLaunchKernelGGL(gwc_volume_kernel, grid, blk, lds, st, ref, tgt, vol, C, H, W, D, G, vol_bstride);
+        else if (vec)
+            hipLaunchKernelGGL(gwc_volume_quad_kernel<true>, grid, blk, lds_q, st, ref, tgt, vol, C, H, W, D, G, vol_bstride, lpad);
+        else
+            hipLaunchKernelGGL(gwc_volume_quad_kernel<false>, grid, blk, lds_q, st, ref, tgt, vol, C, H, W, D, G, vol_bstride, lpad);
+    }
     return dkt_launch_status();
 }
 
