@@ -74,6 +74,8 @@ def _folded_locked(conv, bn):
         f.bias = b.float().contiguous()
     f.padding = conv.padding
     f.stride = conv.stride
+    f.dilation = conv.dilation        # conv2d sends dilated / grouped layers to the vendor library
+    f.groups = conv.groups
     f.key = key
     cache[slot] = f
     return f
@@ -84,7 +86,7 @@ def conv_norm_act(conv, norm, x, relu):
     raft_stereo.py:56-59) is folded into the convolution and the ReLU into its epilogue, which
     removes two full passes over the activation per layer; other norms go through norm_act."""
     if (isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats
-            and isinstance(conv, _Conv2d) and _hip_ok(x) and conv.dilation == (1, 1) and conv.groups == 1
+            and isinstance(conv, nn.Conv2d) and _hip_ok(x) and conv.padding_mode == 'zeros'
             and not (torch.is_grad_enabled() and conv.weight.requires_grad)):
         return conv2d(x, _folded(conv, norm), relu=relu)      # conv2d honours f.stride
     return norm_act(norm, conv(x), relu)

@@ -197,3 +197,19 @@ def igev_loop_inputs(c):
     net = [np.tanh(_synth.normal((B, 128, H >> i, W >> i), s, "net%d" % i)) for i in range(3)]
     inp = [_synth.normal((B, 384, H >> i, W >> i), s, "inp%d" % i, scale=0.5) for i in range(3)]
     return m1, m2, geo, np.abs(disp), coords, net, inp
+
+
+# ---- GwcNet end to end (meta_arch/gwcnet/gwc_main.py:279-326, eval / test_mode) -----------------
+GWCNET_CASES = {
+    "64x128":  dict(seed=6, B=1, H=64, W=128, shift=12, stride=1),
+    "96x160_b2": dict(seed=8, B=2, H=96, W=160, shift=20, stride=2),
+    # BASELINE cfg 5: 540x960 padded to 544x960 (InputPadder divis_by=32), D = 192
+    "544x960": dict(seed=9, B=1, H=544, W=960, shift=40, stride=8),
+}
+GWCNET_WEIGHT_SEED = 17
+
+
+# ---- evaluation chain (tools/evaluate_stereo.py:124-134): pad to /32 -> forward -> unpad ----------
+EVAL_CASES = {
+    "raft_100x187_it4": dict(seed=21, H=100, W=187, shift=12, iters=4),     # neither side divisible by 32
+}

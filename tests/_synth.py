@@ -86,6 +86,9 @@ def state_dict(shapes, seed, dtype_of=None):
             else:
                 b = 1.0 / float(np.sqrt(cin * kh * kw))
                 out[name] = uniform(shape, -b, b, seed, canon)
+        elif leaf == "weight" and len(shape) == 5:
+            # Conv3d / ConvTranspose3d of the 3-D aggregation networks: fan-out normal like gwc_main.py:221-223
+            out[name] = normal(shape, seed, canon, scale=float(np.sqrt(2.0 / (shape[0] * shape[2] * shape[3] * shape[4]))))
         elif leaf == "bias" and len(shape) == 1:
             w = shapes.get(name.rsplit(".", 1)[0] + ".weight")
             fan_in = int(np.prod(tuple(w)[1:])) if w is not None else shape[0]

@@ -81,4 +81,9 @@ def load():
     ns.igev_update = iupdate
     ns.igev_sub = isub
     ns.gwc_sub = gsub
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        from meta_arch.gwcnet.gwc_main import GWCNet
+    ns.GWCNet = GWCNet
     return ns

@@ -472,6 +472,53 @@ def gen_igev_loop(ref):
     save("igev_loop", **out)
 
 
+@torch.no_grad()
+def gen_gwcnet(ref):
+    """GwcNet end to end (BASELINE configs[4]): the reference GWCNet in eval mode, test_mode=True."""
+    import contextlib
+    import io
+    print("GwcNet end to end (reference GWCNet.forward, eval, test_mode)")
+    args = SimpleNamespace(maxdisp=192, use_concat_volume=True, mixed_precision=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref.GWCNet(args)
+    shapes = _synth.shapes_of(model)
+    sd = _synth.torch_state_dict(shapes, _cases.GWCNET_WEIGHT_SEED)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    MANIFEST["gwcnet_state_dict"] = {k: list(v) for k, v in sorted(shapes.items())}
+    out = {}
+    for name, c in _cases.GWCNET_CASES.items():
+        i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+        _, disp = model(T(i1), T(i2), test_mode=True)
+        s = c["stride"]
+        out["%s/disp" % name] = disp.numpy()[:, :, ::s, ::s].copy()
+        out["%s/stride" % name] = np.int64(s)
+        print("   %s: disparity range %.2f .. %.2f" % (name, float(-disp.max()), float(-disp.min())))
+    save("gwcnet", **out)
+
+
+@torch.no_grad()
+def gen_eval(ref):
+    """The evaluator's chain on a size that needs padding: reference InputPadder(divis_by=32) -> reference
+    RAFTStereo.forward(test_mode) -> unpad (tools/evaluate_stereo.py:124-134)."""
+    print("evaluation chain: pad /32 -> RAFT-Stereo -> unpad")
+    cfg = json.load(open(os.path.join(_refimport.REF, "configs", "raft_stereo", "base.json")))
+    model = ref.RAFTStereo(SimpleNamespace(mixed_precision=False, **cfg))
+    sd = _synth.torch_state_dict(_synth.shapes_of(model), _cases.E2E_WEIGHT_SEED)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    out = {}
+    for name, c in _cases.EVAL_CASES.items():
+        i1, i2 = _synth.image_pair(c["seed"], 1, c["H"], c["W"], c["shift"])
+        i1, i2 = np.floor(i1), np.floor(i2).clip(0, 255)          # what an 8-bit image file holds
+        padder = ref.utils.InputPadder(i1.shape, divis_by=32)
+        p1, p2 = padder.pad(T(i1), T(i2))
+        _, flow_pr = model(p1, p2, iters=c["iters"], test_mode=True)
+        out["%s/flow" % name] = padder.unpad(flow_pr).numpy()
+        out["%s/padded_shape" % name] = np.array(p1.shape[-2:], np.int64)
+    save("eval", **out)
+
+
 def gen_sampler(ref):
     print("sampler bit-exactness (C oracle vs reference bilinear_sampler)")
     g = _synth.rng(99, "sampler")
@@ -495,7 +542,7 @@ def main():
     ref = _refimport.load()
     only = set(sys.argv[1:])
     gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd), ("geo_bwd", gen_geo_bwd), ("upsample", gen_upsample), ("files", gen_files),
-            ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e)]
+            ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e), ("gwcnet", gen_gwcnet), ("eval", gen_eval)]
     for name, fn in gens:
         if not only or name in only:
             fn(ref)

@@ -456,3 +456,49 @@ def test_otf_lookup_paths(mode):
     d = maxabs(got, want)
     print("otf %s: max|d| %.3e (scale %.2f)" % (mode, d, scale))
     assert d <= 4e-6 * scale
+
+
+# ---------------------------------------------------------------------------------
+# GwcNet end to end (BASELINE configs[4]) and the evaluation chain
+# ---------------------------------------------------------------------------------
+def _gwcnet():
+    from dkt_stereo_amd.gwcnet import GWCNet
+    m = GWCNet()
+    m.load_state_dict(_synth.torch_state_dict(_synth.shapes_of(m), _cases.GWCNET_WEIGHT_SEED), strict=True)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", list(_cases.GWCNET_CASES))
+@torch.no_grad()
+def test_gwcnet_end_to_end(name, golden):
+    """Feature extraction on this library's convolutions, gwc(40 groups) + concat volume in one buffer, 3-D
+    aggregation on the vendor library, soft-argmin: final disparity within 1e-3 of the reference GWCNet."""
+    c = _cases.GWCNET_CASES[name]
+    model = _gwcnet()
+    i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+    none, disp = model(G(i1), G(i2), test_mode=True)
+    g = golden("gwcnet")
+    s = int(g[name + "/stride"])
+    d = maxabs(disp[:, :, ::s, ::s], g[name + "/disp"])
+    print("gwcnet %s: max|d| %.3e" % (name, d))
+    assert none is None and disp.shape == (c["B"], 1, c["H"], c["W"])
+    assert d <= 1e-3
+
+
+@torch.no_grad()
+def test_evaluation_chain_matches_reference(golden, tmp_path):
+    """Files on disk -> frame_utils readers -> InputPadder(32) -> RAFTStereo -> unpad: the prediction equals the
+    reference's own chain on the same pair (fixture), and EPE / D1 are what the metric says."""
+    from test_host_round2 import _write_kitti_like
+    from dkt_stereo_amd import evaluate
+    c = _cases.EVAL_CASES["raft_100x187_it4"]
+    paths, disp = _write_kitti_like(str(tmp_path), c["seed"], c["H"], c["W"], c["shift"])
+    model, _ = _raft()
+    res = evaluate.validate(model, [tuple(paths)], iters=c["iters"], device=DEV, keep=True)
+    pr = res["predictions"][0]
+    g = golden("eval")
+    assert maxabs(pr[None], g["raft_100x187_it4/flow"]) <= 1e-3
+    err = np.abs(pr[0].numpy() + disp)
+    val = disp > 0
+    assert abs(res["epe"] - err[val].mean()) <= 1e-4
+    assert abs(res["d1"] - 100.0 * (err[val] > 3.0).mean()) <= 1e-9
