@@ -15,10 +15,14 @@ data-path collective); the final disparity maps are gathered to rank 0 over
 RCCL inside the timed region, as a real sharded evaluation would.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the dominant kernel (update-block convolution, MFMA-bound): flops per
-                launch / its average launch duration measured live with HIP events on
-                the launch stream; roofline_lookup: the corr-lookup kernel (HBM-bound,
-                the kernel BASELINE.json's north_star sets the 60 % target for)
+  roofline      the dominant kernel (update-block convolution, MFMA-bound): algorithmic flops
+                per launch / its average launch duration measured live with HIP events on the
+                launch stream (frac = frac_algorithmic; mfma_issue_frac counts the 3 fp16 MFMA
+                passes per product); roofline_lookup: the corr-lookup kernel (HBM-bound, the
+                kernel BASELINE.json's north_star sets the 60 % target for) -- since round 2 it
+                is fused with the 1x1 layer that consumes it.  `traffic`: 2 x FETCH_SIZE +
+                WRITE_SIZE from profiles/r02_hbm_traffic.txt (separate rocprofv3 --pmc passes
+                of the same kernels and shapes, calibrated on known-traffic streams)
   cpu_baseline  oracle/torch_oracle.py (pure-PyTorch CPU port of the reference,
                 pinned to it by tests/golden) timed on this host, bounded sample
 """
@@ -56,10 +60,12 @@ def parse():
     return p.parse_args()
 
 
-def lookup_bytes_per_launch(n_pixels, L=4, r=4):
-    """per pixel L*(K+1)*4 read + 4 (coord) + L*K*4 written = 308 B at L=4, r=4."""
+def lookup_bytes_per_launch(n_pixels, L=4, r=4, cout=None):
+    """per pixel L*(K+1)*4 read + 4 (coord) + L*K*4 written = 308 B at L=4, r=4.
+    With `cout` (the lookup fused with the 1x1 layer that consumes it, dkt_corr1d_lookup_conv1x1): the
+    L*K-channel lookup is never written; cout*4 B of the layer's output are: 160 + 4 + 256 = 420 B at cout=64."""
     K = 2 * r + 1
-    return n_pixels * (L * (K + 1) * 4 + 4 + L * K * 4)
+    return n_pixels * (L * (K + 1) * 4 + 4 + (cout if cout is not None else L * K) * 4)
 
 
 class TimedCorr:
@@ -191,11 +197,27 @@ def main():
         # gru08 z|r, 384->256 3x3 -- and (b) the correlation lookup (same stream, same inputs,
         # same kernels).  The cost of an empty event pair is measured and subtracted.
         model.use_hip_graph = False
-        rs.CORR_IMPLEMENTATIONS = {k: timed_factory(v) for k, v in real_impls.items()}
         look_events.clear()
         conv_events = []
+        import dkt_stereo_amd.corr as dcorr
         import dkt_stereo_amd.update as upd
         real_gate_zr = upd.conv2d_gate_zr
+        real_fused = dcorr.CorrBlock1D.lookup_conv1x1
+        fused_lookup = model.fuse_lookup
+
+        def timed_fused(self_, coords, layer, relu=True, tap=False):
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            y = real_fused(self_, coords, layer, relu=relu, tap=tap)
+            eb.record()
+            if y is not None:
+                look_events.append((ea, eb))
+            return y
+
+        if fused_lookup:
+            dcorr.CorrBlock1D.lookup_conv1x1 = timed_fused
+        else:
+            rs.CORR_IMPLEMENTATIONS = {k: timed_factory(v) for k, v in real_impls.items()}
 
         def timed_gate_zr(x, layer, cz, cr, h):
             # gru08: merged z|r convolution (384 -> 256, 3x3) with the gate epilogue, finest scale
@@ -213,6 +235,7 @@ def main():
         step()
         torch.cuda.synchronize()
         upd.conv2d_gate_zr = real_gate_zr
+        dcorr.CorrBlock1D.lookup_conv1x1 = real_fused
         rs.CORR_IMPLEMENTATIONS = real_impls
         model.use_hip_graph = True
         empty = []
@@ -243,7 +266,7 @@ def main():
 
     n_pix = B * h4 * w4
     look_avg_ms = sum(look_ms) / max(len(look_ms), 1)
-    alg = lookup_bytes_per_launch(n_pix)
+    alg = lookup_bytes_per_launch(n_pix, cout=64 if fused_lookup else None)
     achieved = alg / (look_avg_ms * 1e-3) / 1e9 if look_avg_ms > 0 else 0.0
     passes = {"f16x3": 3, "f16x2": 2, "f16": 1}.get(_conv.get_backend(), 1)
     conv_avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
@@ -253,7 +276,7 @@ def main():
     # rocprofv3 runs of the same kernels on the same shapes); None when the file is absent
     traffic = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
             traffic = json.load(f)
     except (OSError, ValueError):
         pass
@@ -300,10 +323,12 @@ def main():
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
         # the kernel BASELINE.json's north_star sets the HBM target for
-        "roofline_lookup": {"kernel": "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
+        "roofline_lookup": {"kernel": ("corr_feat_kernel<4,4,2> (dkt_corr1d_lookup_conv1x1): pyramid lookup fused with "
+                                       "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA") if fused_lookup
+                            else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": traffic.get("lookup_b1_bytes") if default_shape else None,
+                            "traffic": traffic.get("lookup_conv1x1_b1_bytes" if fused_lookup else "lookup_b1_bytes") if default_shape else None,
                             "traffic_source": traffic.get("source") if default_shape else None,
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
                             "launches_timed": len(look_ms)},

@@ -61,12 +61,10 @@ def cfg3():
 
     def pair():
         build_gwc_volume(ml, mr, 48, 8)                       # igev_stereo.py:169
-        geo_fn = Combined_Geo_Encoding_Volume(ml, mr, geo, radius=4, num_levels=2)   # :192-193
-        cache.setdefault("geo", geo_fn)
-        if cache["geo"] is not geo_fn:                        # same shapes: refill the first volume object in place
-            for dst, src in zip(cache["geo"].geo_volume_pyramid + cache["geo"].init_corr_pyramid,
-                                geo_fn.geo_volume_pyramid + geo_fn.init_corr_pyramid):
-                dst.copy_(src)
+        if "geo" not in cache:
+            cache["geo"] = Combined_Geo_Encoding_Volume(ml, mr, geo, radius=4, num_levels=2)   # :192-193
+        else:
+            cache["geo"].rebuild(ml, mr, geo)                 # same shapes: pyramids refilled in place
         return igev_iterate(blk, cache["geo"], disp0, coords, net0, inp, iters, cache=cache)[0]   # :199-210
 
     t = sync_time(pair, 3, 2)
@@ -103,11 +101,38 @@ def cfg5():
     t_sep = sync_time(lambda: torch.cat((build_gwc_volume(fl, fr, 48, 40), build_concat_volume(cl, cr, 48)), 1), 20, 3)
     t_fused = sync_time(lambda: build_gwc_concat_volume(fl, fr, cl, cr, 48, 40), 20, 3)
     out_bytes = 64 * 48 * H * W * 4
+    # end to end: dkt_stereo_amd.gwcnet.GWCNet (features on this library's convolutions, fused volume, 3-D
+    # aggregation on the vendor library, soft-argmin), 544x960 = 540x960 padded to /32
+    from dkt_stereo_amd.gwcnet import GWCNet
+    m = GWCNet()
+    m.load_state_dict(_synth.torch_state_dict(_synth.shapes_of(m), 17))
+    m.to(DEV).eval()
+    i1, i2 = _synth.image_pair(9, 1, 544, 960, 40)
+    i1, i2 = torch.from_numpy(i1).to(DEV), torch.from_numpy(i2).to(DEV)
+    torch.backends.cudnn.benchmark = True
+    t_e2e = sync_time(lambda: m(i1, i2, test_mode=True), 3, 2)
+    feats = {}
+
+    def stage(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        feats[name] = 1e3 * (time.perf_counter() - t0)
+        return r
+    n1 = (2 * (i1 / 255.0) - 1.0).contiguous()
+    n2 = (2 * (i2 / 255.0) - 1.0).contiguous()
+    f = stage("features_ms", lambda: m.feature_extraction(torch.cat([n1, n2], 0)))
+    fL = {k: v[:1] for k, v in f.items()}
+    fR = {k: v[1:] for k, v in f.items()}
+    vol = stage("volume_ms", lambda: m.build_volume(fL, fR))
+    stage("aggregation_softargmin_ms", lambda: m.cost_regularization(vol))
     print(json.dumps({"config": "cfg5 GwcNet 544x960 (136x240 @1/4): gwc volume 320ch/40 groups + concat volume "
-                                "2x12ch, 48 planes -> (1,64,48,136,240)",
+                                "2x12ch, 48 planes -> (1,64,48,136,240); end to end with 3-D aggregation on the vendor library",
                       "us_separate_plus_cat": 1e6 * t_sep, "us_fused_buffer": 1e6 * t_fused,
-                      "output_GB_per_s_fused": out_bytes / t_fused / 1e9, "dtype": "f32", "data": "synthetic"}),
-          flush=True)
+                      "output_GB_per_s_fused": out_bytes / t_fused / 1e9,
+                      "e2e_ms_per_pair": 1e3 * t_e2e, "e2e_pairs_per_s": 1.0 / t_e2e, "e2e_stages": feats,
+                      "dtype": "f32", "data": "synthetic"}), flush=True)
 
 
 if __name__ == "__main__":
