@@ -350,6 +350,20 @@ def _launch_pair(da, db, passes, ref):
     _ffi.check(rc, "dkt_conv2d_f16s_pair")
 
 
+def conv2d_pair(a, b):
+    """Two independent stride-1 convolutions (bias + optional ReLU) in one launch.  a, b = (x, layer, relu);
+    the layers must satisfy ``pair_eligible``.  Returns (y_a, y_b)."""
+    res, descs, passes = [], [], None
+    for x, layer, relu in (a, b):
+        op = _Operands(x, layer)
+        out = torch.empty((op.B, op.cout, op.H, op.W), device=op.device, dtype=torch.float32)
+        descs.append(_desc(op, out, relu=relu))
+        res.append(out)
+        passes = op.passes
+    _launch_pair(descs[0], descs[1], passes, res[0])
+    return res
+
+
 def conv2d_gate_zr_pair(a, b):
     """conv2d_gate_zr for two independent GRUs in one launch.  a, b = (x, zr_layer, cz, cr, h);
     returns ((z_a, rh_a), (z_b, rh_b))."""

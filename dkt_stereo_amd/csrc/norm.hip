@@ -199,25 +199,43 @@ extern "C" int dkt_add_relu(const float *a, const float *b, float *y, long n, in
 // avg_pool2d(x, 3, stride=2, padding=1), count_include_pad=True (divide by 9 always).
 // Sum order: rows top to bottom, columns left to right (ATen's loop order), then * (1/9)?
 // ATen divides the sum by the pool size: sum / 9.
+// grid.y = output row of a plane (plane * Ho + oy), threads along ox: no per-thread division; the nine loads are
+// unconditional (clamped index, zero selected afterwards -- s + 0.0f is s) and in flight together.
 __global__ __launch_bounds__(256) void pool2x_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                      int H, int W, int Ho, int Wo, long planes) {
-    const long total = planes * Ho * Wo;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ox = (int)(i % Wo);
-        const int oy = (int)((i / Wo) % Ho);
-        const long pl = i / ((long)Wo * Ho);
-        const float *p = x + pl * H * W;
-        float s = 0.0f;
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    if (ox >= Wo) return;
+    constexpr int RB = 4;                                  // output rows per step: 36 loads in flight per thread
+    const long nrows = planes * Ho;
+    for (long row0 = (long)blockIdx.y * RB; row0 < nrows; row0 += (long)gridDim.y * RB) {
+        float v[RB][9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int iy = 2 * oy - 1 + dy;
+        for (int r = 0; r < RB; ++r) {
+            const long row = min(row0 + r, nrows - 1);
+            const long pl = row / Ho;                      // block-uniform
+            const int oy = (int)(row - pl * Ho);
+            const float *p = x + pl * H * W;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ix = 2 * ox - 1 + dx;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) s = __fadd_rn(s, p[(long)iy * W + ix]);
+            for (int dy = 0; dy < 3; ++dy) {
+                const int iy = 2 * oy - 1 + dy;
+                const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int ix = 2 * ox - 1 + dx;
+                    const bool ok = yok && ix >= 0 && ix < W;
+                    const float t = p[(long)(yok ? iy : 0) * W + (ix >= 0 && ix < W ? ix : 0)];
+                    v[r][dy * 3 + dx] = ok ? t : 0.0f;
+                }
             }
         }
-        y[i] = __fdiv_rn(s, 9.0f);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (row0 + r >= nrows) break;
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s = __fadd_rn(s, v[r][k]);
+            y[(row0 + r) * Wo + ox] = __fdiv_rn(s, 9.0f);
+        }
     }
 }
 
@@ -226,9 +244,9 @@ extern "C" int dkt_pool2x(const float *x, float *y, long planes, int H, int W, i
     if (planes <= 0 || H <= 0 || W <= 0) return DKT_E_SHAPE;
     DKT_ENTER(device);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    long blocks = (planes * Ho * Wo + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    long rows = (planes * Ho + 3) / 4;                     // 4 output rows per block step
+    if (rows > 65535) rows = 65535;
+    hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)((Wo + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                        x, y, H, W, Ho, Wo, planes);
     return dkt_launch_status();
 }
@@ -238,42 +256,66 @@ extern "C" int dkt_pool2x(const float *x, float *y, long planes, int H, int W, i
 //   out = l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
 // One thread = 4 adjacent outputs of one row (float4 store when Wo % 4 == 0); the row weights
 // and the two source-row pointers are shared by the four.
-__global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ x, float *__restrict__ y,
+// grid.y = output row of a plane, threads along quads of ox: no per-thread division.
+__global__ __launch_bounds__(128) void interp_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                      int H, int W, int Ho, int Wo, float sy, float sx, long planes) {
     const int Wq = (Wo + 3) / 4;
-    const long total = planes * Ho * Wq;
+    const int oq = blockIdx.x * 128 + threadIdx.x;
+    if (oq >= Wq) return;
     const bool vec = (Wo & 3) == 0 && (((uintptr_t)y) & 15) == 0;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int oq = (int)(i % Wq);
-        const int oy = (int)((i / Wq) % Ho);
-        const long pl = i / ((long)Wq * Ho);
-        const float *p = x + pl * H * W;
-        const float fy = __fmul_rn(sy, (float)oy);
-        const int y0 = (int)fy;
-        const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
-        const float ly1 = __fsub_rn(fy, (float)y0);
-        const float ly0 = __fsub_rn(1.0f, ly1);
-        const float *r0 = p + (long)y0 * W, *r1 = p + (long)y1 * W;
-        float o[4];
+    // the four columns' source indices and weights do not depend on the row
+    int x0[4], x1[4];
+    float lx0[4], lx1[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ox = min(4 * oq + k, Wo - 1);
-            const float fx = __fmul_rn(sx, (float)ox);
-            const int x0 = (int)fx;
-            const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
-            const float lx1 = __fsub_rn(fx, (float)x0);
-            const float lx0 = __fsub_rn(1.0f, lx1);
-            const float top = __fadd_rn(__fmul_rn(lx0, r0[x0]), __fmul_rn(lx1, r0[x1]));
-            const float bot = __fadd_rn(__fmul_rn(lx0, r1[x0]), __fmul_rn(lx1, r1[x1]));
-            o[k] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+    for (int k = 0; k < 4; ++k) {
+        const int ox = min(4 * oq + k, Wo - 1);
+        const float fx = __fmul_rn(sx, (float)ox);
+        x0[k] = (int)fx;
+        x1[k] = x0[k] + (x0[k] < W - 1 ? 1 : 0);
+        lx1[k] = __fsub_rn(fx, (float)x0[k]);
+        lx0[k] = __fsub_rn(1.0f, lx1[k]);
+    }
+    constexpr int RB = 4;                                  // output rows per step: 16 loads per row in flight together
+    const long nrows = planes * Ho;
+    for (long row0 = (long)blockIdx.y * RB; row0 < nrows; row0 += (long)gridDim.y * RB) {
+        float a0[RB][4], a1[RB][4], b0[RB][4], b1[RB][4], ly0[RB], ly1[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const long row = min(row0 + r, nrows - 1);
+            const long pl = row / Ho;                      // block-uniform
+            const int oy = (int)(row - pl * Ho);
+            const float *p = x + pl * H * W;
+            const float fy = __fmul_rn(sy, (float)oy);
+            const int y0 = (int)fy;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+            ly1[r] = __fsub_rn(fy, (float)y0);
+            ly0[r] = __fsub_rn(1.0f, ly1[r]);
+            const float *r0 = p + (long)y0 * W, *r1 = p + (long)y1 * W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a0[r][k] = r0[x0[k]]; a1[r][k] = r0[x1[k]];
+                b0[r][k] = r1[x0[k]]; b1[r][k] = r1[x1[k]];
+            }
         }
-        float *q = y + (pl * Ho + oy) * (long)Wo + 4 * oq;
-        if (vec) {
-            *(float4 *)q = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (4 * oq + k < Wo) q[k] = o[k];
+        for (int r = 0; r < RB; ++r) {
+            const long row = row0 + r;
+            if (row >= nrows) break;
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float top = __fadd_rn(__fmul_rn(lx0[k], a0[r][k]), __fmul_rn(lx1[k], a1[r][k]));
+                const float bot = __fadd_rn(__fmul_rn(lx0[k], b0[r][k]), __fmul_rn(lx1[k], b1[r][k]));
+                o[k] = __fadd_rn(__fmul_rn(ly0[r], top), __fmul_rn(ly1[r], bot));
+            }
+            float *q = y + row * (long)Wo + 4 * oq;
+            if (vec) {
+                *(float4 *)q = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * oq + k < Wo) q[k] = o[k];
+            }
         }
     }
 }
@@ -285,9 +327,10 @@ extern "C" int dkt_interp_bilinear(const float *x, float *y, long planes, int H,
     DKT_ENTER(device);
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.0f;
     const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.0f;
-    long blocks = (planes * Ho * ((Wo + 3) / 4) + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(interp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    long rows = (planes * Ho + 3) / 4;                     // 4 output rows per block step
+    if (rows > 65535) rows = 65535;
+    const int Wq = (Wo + 3) / 4;
+    hipLaunchKernelGGL(interp_kernel, dim3((unsigned)((Wq + 127) / 128), (unsigned)rows), dim3(128), 0, (hipStream_t)stream,
                        x, y, H, W, Ho, Wo, sy, sx, planes);
     return dkt_launch_status();
 }

@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import (_CACHE_LOCK, conv2d, conv2d_gate_out, conv2d_gate_out_pair, conv2d_gate_zr, conv2d_gate_zr_pair,
+from .conv import (_CACHE_LOCK, conv2d, conv2d_gate_out, conv2d_gate_out_pair, conv2d_gate_zr, conv2d_gate_zr_pair, conv2d_pair,
                    get_backend, hip_eligible, pair_eligible)
 
 
@@ -75,6 +75,10 @@ def harness(**switches):
 #: evaluate the GRU gates inside the convolution epilogues (dkt_conv2d_f16s_gate_zr/_out)
 #: instead of the two streaming gate kernels
 FUSE_GATES = os.environ.get("DKT_FUSE_GATES", "1") != "0"
+
+
+#: the motion encoder's two independent 64 -> 64 layers (convc2, convf2 / convd2) share one launch
+PAIR_ENCODER = os.environ.get("DKT_PAIR_ENCODER", "1") != "0"
 
 
 def _batch_dense(t, hw):
@@ -251,9 +255,15 @@ class BasicMotionEncoder(nn.Module):
             cor = conv2d(self._cor1(corr), self.convc2, relu=True)
             cur.wait_stream(aux)
         else:
-            cor = conv2d(self._cor1(corr), self.convc2, relu=True)
-            flo = conv2d(conv2d(flow, getattr(self, self._branch[0]), relu=True),
-                         getattr(self, self._branch[1]), relu=True)
+            cor1 = self._cor1(corr)
+            flo1 = conv2d(flow, getattr(self, self._branch[0]), relu=True)
+            second = getattr(self, self._branch[1])
+            if PAIR_ENCODER and flow.is_cuda and pair_eligible(self.convc2, second):
+                # the two branches' 3x3 layers (64 -> 64 each) are independent: one launch
+                cor, flo = conv2d_pair((cor1, self.convc2, True), (flo1, second, True))
+            else:
+                cor = conv2d(cor1, self.convc2, relu=True)
+                flo = conv2d(flo1, second, relu=True)
         # [conv output (126/127 ch) | flow]: the convolution writes straight into the first
         # channels of the 128-channel motion-feature buffer (no torch.cat of the big part)
         B, _, H, W = flow.shape

@@ -9,7 +9,8 @@ import bench_kernels as bk
 from dkt_stereo_amd import conv
 conv.set_backend("f16x3")
 name = os.path.basename(os.environ.get("DKT_LIB_PATH", "product"))
-CASES = (("convc1", 64, [36], 1, 184, 312), ("convc2", 64, [64], 3, 184, 312), ("enc.conv", 126, [64, 64], 3, 184, 312),
+import os as _os
+CASES = (("enc64@736", 64, [64], 3, 736, 1248), ("enc96@368", 96, [96], 3, 368, 624), ("enc128@184", 128, [128], 3, 184, 312)) if _os.environ.get("ENC") else (("convc1", 64, [36], 1, 184, 312), ("convc2", 64, [64], 3, 184, 312), ("enc.conv", 126, [64, 64], 3, 184, 312),
          ("gru08.zr", 256, [128, 128, 128], 3, 184, 312), ("gru08.q", 128, [128, 128, 128], 3, 184, 312),
          ("fh.conv1", 256, [128], 3, 184, 312), ("fh.conv2", 2, [256], 3, 184, 312),
          ("gru16.zr", 256, [128, 128, 128], 3, 92, 156), ("gru32.zr", 256, [128, 128], 3, 46, 78))
