@@ -247,6 +247,34 @@ def main():
         torch.cuda.synchronize()
         ev_overhead_ms = sorted(x.elapsed_time(y) for x, y in empty)[len(empty) // 2]
         look_ms = [max(a.elapsed_time(b) - ev_overhead_ms, 1e-6) for a, b in look_events]
+        # The lookup kernel is shorter than the host cost of launching it from Python (15-20 us), so an event
+        # pair around an eager launch mostly times the host.  It is therefore timed as the timed region runs it:
+        # back-to-back launches replayed from a HIP graph on the launch stream (32 launches per replay, 8
+        # replays), on the pyramid and coordinates the timed steps left behind.
+        st = model._graph_state
+        if st is not None:
+            blk_, c1_ = st["corr"], st["coords1"]
+            layer_ = model.update_block.encoder.convc1
+            if fused_lookup:
+                one = lambda: blk_.lookup_conv1x1(c1_, layer_)          # noqa: E731
+            else:
+                one = lambda: blk_(c1_)                                 # noqa: E731
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            gl = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gl):
+                for _ in range(32):
+                    one()
+            gl.replay()
+            torch.cuda.synchronize()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            for _ in range(8):
+                gl.replay()
+            eb.record()
+            torch.cuda.synchronize()
+            look_ms = [ea.elapsed_time(eb) / 256.0] * 256
         conv_ms = [max(a.elapsed_time(b) - ev_overhead_ms, 1e-6) for a, b in conv_events]
 
         # hot path alone (what the C ABI covers + the update block), encoders excluded

@@ -42,6 +42,21 @@ def make_args(**overrides):
     return SimpleNamespace(**cfg)
 
 
+class _Precomputed:
+    """relu(convc1(lookup)) computed ahead of the motion encoder's call (stands in for the deferred lookup)."""
+
+    def __init__(self, cor1):
+        self.cor1 = cor1
+        self.is_cuda = cor1.is_cuda
+        self.device = cor1.device
+
+    def materialize(self):
+        raise RuntimeError("the lookup tensor was fused away (DKT_FUSE_LOOKUP=0 keeps it)")
+
+    def conv1x1(self, layer, relu=True):
+        return self.cor1
+
+
 #: module -> {thread id: captured-iteration state}.  Kept outside the module (graphs and static buffers
 #: are neither picklable nor deep-copyable) and per thread (two threads driving one module each need
 #: their own static buffers and capture).
@@ -211,6 +226,14 @@ class RAFTStereo(nn.Module):
         with harness(inplace_state=True, side_stream=False, branch_streams=self.branch_streams,
                      before_fine=lambda: main.wait_event(done16), fine_interp=lambda: up16[0],
                      pair_coarse=pair, coarse_pool=lambda: pool16[0]):
+            # The lookup (fused with convc1) is launched BEFORE the fork: it is a 15-us latency-bound kernel, and
+            # beside gru16's convolutions -- which occupy every CU's register file -- it would be stretched to
+            # 50+ us without the pair finishing any earlier.
+            corr = self._lookup(corr_fn, coords1)
+            if hasattr(corr, "materialize"):
+                cor1 = ub.encoder._cor1(corr)
+                corr = _Precomputed(cor1)
+            flow = coords1 - coords0
             side.wait_stream(main)                   # fork
             with torch.cuda.stream(side):
                 ub(nets, inp_list, iter32=False, iter16=True, iter08=False, update=False)      # gru16(i)
@@ -225,8 +248,6 @@ class RAFTStereo(nn.Module):
                 done16.record(side)
                 if not last and not pair:
                     ub(nets, inp_list, iter32=True, iter16=False, iter08=False, update=False)  # gru32(i+1)
-            corr = self._lookup(corr_fn, coords1)
-            flow = coords1 - coords0
             nets, up_mask, delta_flow = ub(nets, inp_list, corr, flow, iter32=False, iter16=False,
                                            need_mask=need_mask)
             main.wait_stream(side)                   # join

@@ -28,7 +28,7 @@ def G(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-def timeit(fn, n=50, warm=5):
+def timeit(fn, n=50, warm=5, graph=True):
     """Microseconds per call.  The calls are captured into a HIP graph (10 per replay) so that host
     launch cost (15-20 us per Python-level call) does not hide kernels shorter than that; callables
     that cannot be captured (autograd, host syncs) are timed as back-to-back eager launches."""
@@ -36,7 +36,7 @@ def timeit(fn, n=50, warm=5):
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if os.environ.get("DKT_BENCH_EAGER", "0") != "1":
+    if graph and os.environ.get("DKT_BENCH_EAGER", "0") != "1":
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -96,6 +96,17 @@ def bench_lookup():
                 report("lookup rows v%s B=%d %s" % (variant, B, kind),
                        timeit(lambda: _lookup(blk.corr_pyramid, coords, 4, W), n=200), bytes_=alg)
             report("lookup skew    B=%d %s" % (B, kind), timeit(lambda: blk(coords), n=200), bytes_=alg)
+            c1 = torch.nn.Conv2d(36, 64, 1).to(DEV)
+            report("lookup + convc1 fused B=%d %s" % (B, kind), timeit(lambda: blk.lookup_conv1x1(coords, c1), n=200),
+                   bytes_=n * 420)
+            if kind == "smooth":
+                from dkt_stereo_amd.corr import PytorchAlternateCorrBlock1D
+                coords[:, 1] = torch.arange(H, device=DEV).float().view(1, H, 1)
+                alt = PytorchAlternateCorrBlock1D(f1, f2, num_levels=4, radius=4)
+                # algorithmic bytes: both feature maps once per level pyramid (f1 x L, pooled f2 once) + coords + output
+                alt_bytes = B * C * H * W * 4 * (4 + 1.875) + n * (8 + 144)
+                report("lookup on the fly (alt) B=%d %s" % (B, kind), timeit(lambda: alt(coords), n=50), bytes_=alt_bytes)
+                del alt
         os.environ.pop("DKT_LOOKUP_VARIANT", None)
         del blk, f1, f2
 
@@ -336,10 +347,10 @@ def bench_next():
     go = torch.randn_like(out)
     pyr_bytes = 4 * H * W * (312 + 156 + 78 + 39)
     report("lookup backward (zero-fill + scatter, 4 levels)",
-           timeit(lambda: torch.autograd.grad(out, cb.corr_pyramid, go, retain_graph=True), n=30),
+           timeit(lambda: torch.autograd.grad(out, cb.corr_pyramid, go, retain_graph=True), n=30, graph=False),
            bytes_=pyr_bytes + out.numel() * 4)
     report("lookup + pyramid + corr backward -> grad fmaps",
-           timeit(lambda: torch.autograd.grad(out, [a1, b1], go, retain_graph=True), n=20),
+           timeit(lambda: torch.autograd.grad(out, [a1, b1], go, retain_graph=True), n=20, graph=False),
            flops=2 * 2.0 * H * W * W * 256)
 
 
