@@ -20,7 +20,7 @@ import torch
 from . import conv as _conv
 import os
 
-from .update import FUSE_GATES, _side_stream, capture_graph, harness, interp, pool2x
+from .update import FUSE_GATES, _side_stream, GPU_GUARD, capture_graph, harness, interp, pool2x, replay_graph
 
 #: the coarsest GRU of the next iteration shares the finest GRU's two launches (dkt_conv2d_f16s_pair)
 PAIR_GRUS = os.environ.get("DKT_PAIR_GRUS", "1") != "0"
@@ -99,6 +99,11 @@ def igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, it
     weights reuse the captured graph (a new geometry volume of the same shapes is copied into the cached
     one's buffers; to avoid that copy keep ONE volume and call its ``rebuild``); without `cache` every call
     captures anew.  ``slow_fast_gru`` runs the plain loop (igev_stereo.py:204-207)."""
+    with GPU_GUARD.shared():
+        return _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph, cache)
+
+
+def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph, cache):
     n = update_block.args.n_gru_layers
     pipelined = (use_hip_graph and init_disp.is_cuda and iters >= 3 and n == 3
                  and not getattr(update_block.args, "slow_fast_gru", False) and update_block.side_stream)
@@ -146,6 +151,6 @@ def igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, it
             _body(ub, st, False, False)
         st.graph = g                                 # (capturing records, it does not execute)
     for _ in range(iters - 1 - done):
-        st.graph.replay()
+        replay_graph(st.graph)
     mask = _body(ub, st, True, True)
     return st.disp.clone(), mask, [t.clone() for t in st.net]

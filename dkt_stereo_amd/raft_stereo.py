@@ -25,7 +25,7 @@ from . import _ffi
 from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
 from .extractor import BasicEncoder, MultiBasicEncoder
-from .update import FUSE_GATES, BasicMultiUpdateBlock, _side_stream, capture_graph, harness, interp, pool2x
+from .update import FUSE_GATES, BasicMultiUpdateBlock, _side_stream, GPU_GUARD, capture_graph, harness, interp, pool2x, replay_graph
 from . import conv as _conv
 from .utils import coords_grid
 
@@ -145,8 +145,9 @@ class RAFTStereo(nn.Module):
         up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
         return up.reshape(N, D, factor * H, factor * W)
 
-    #: replay the GRU iteration from a captured HIP graph (one capture per input shape)
-    use_hip_graph = True
+    #: replay the GRU iteration from a captured HIP graph (one capture per input shape and weight set;
+    #: DKT_HIP_GRAPH=0 runs every iteration eagerly)
+    use_hip_graph = os.environ.get("DKT_HIP_GRAPH", "1") != "0"
     #: hand the motion encoder a deferred lookup: lookup + convc1 run as one kernel
     #: (dkt_corr1d_lookup_conv1x1); DKT_FUSE_LOOKUP=0 keeps the two launches
     fuse_lookup = os.environ.get("DKT_FUSE_LOOKUP", "1") != "0"
@@ -308,7 +309,7 @@ class RAFTStereo(nn.Module):
                 step(False)
             st["graph"] = g
         for _ in range(iters - 1 - done):
-            st["graph"].replay()
+            replay_graph(st["graph"])
         up_mask = step(True)
         flow = st["coords1"] - st["coords0"]
         return flow, self.upsample_flow(flow, up_mask)[:, :1]
@@ -354,9 +355,11 @@ class RAFTStereo(nn.Module):
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
         if not test_mode:
             raise NotImplementedError("dkt_stereo_amd.RAFTStereo is the inference (test_mode=True) path")
-        fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
-        flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
-        if self.check_finite and not bool(torch.isfinite(flow_up).all()):
+        with GPU_GUARD.shared():                      # another thread's graph capture waits for this pass, and vice versa
+            fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
+            flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+            finite = (not self.check_finite) or bool(torch.isfinite(flow_up).all())
+        if not finite:
             raise _ffi.DktError(
                 "RAFTStereo.forward produced non-finite disparities: an activation left the range of the "
                 "split-fp16 convolutions (or the inputs were not finite).  Run one forward under "

@@ -47,16 +47,75 @@ class _Harness(threading.local):
 
 
 _HARNESS = _Harness()
-#: stream captures are serialised across threads and run in thread-local capture mode (another thread's
-#: allocations or launches on the same device must not invalidate a capture in progress)
-CAPTURE_LOCK = threading.Lock()
+class _CaptureGuard:
+    """Keeps every other thread's GPU work of this library out of the way while one thread captures a HIP graph.
+
+    A stream capture on ROCm 7.2 is invalidated by "unsafe" runtime calls of OTHER threads on the device -- a host
+    synchronisation (``forward`` checks its result), a fresh hipMalloc of the caching allocator -- even in
+    thread-local capture mode (observed: hipErrorStreamCaptureUnsupported in the bystander,
+    hipErrorStreamCaptureInvalidated in the capturing thread).  The reference runs replicas from one Python
+    thread per GPU (tools/ft_dkt.py:119), so: a forward pass holds the guard SHARED; a capture upgrades to
+    EXCLUSIVE, i.e. waits until no other forward is in flight and keeps new ones out for the few milliseconds it
+    takes.  Captures happen once per (thread, shape, weight set).  Re-entrant per thread."""
+
+    def __init__(self):
+        self._cv = threading.Condition()
+        self._readers = 0
+        self._writer = False
+        self._waiting_writers = 0
+        self._tls = threading.local()
+
+    @contextlib.contextmanager
+    def shared(self):
+        depth = getattr(self._tls, "depth", 0)
+        if depth == 0:
+            with self._cv:
+                while self._writer or self._waiting_writers:
+                    self._cv.wait()
+                self._readers += 1
+        self._tls.depth = depth + 1
+        try:
+            yield
+        finally:
+            self._tls.depth = depth
+            if depth == 0:
+                with self._cv:
+                    self._readers -= 1
+                    self._cv.notify_all()
+
+    @contextlib.contextmanager
+    def exclusive(self):
+        held = getattr(self._tls, "depth", 0) > 0        # this thread is inside a forward: give its slot back
+        with self._cv:
+            if held:
+                self._readers -= 1
+            self._waiting_writers += 1
+            while self._writer or self._readers:
+                self._cv.wait()
+            self._waiting_writers -= 1
+            self._writer = True
+        try:
+            yield
+        finally:
+            with self._cv:
+                self._writer = False
+                if held:
+                    self._readers += 1
+                self._cv.notify_all()
+
+
+GPU_GUARD = _CaptureGuard()
 
 
 @contextlib.contextmanager
 def capture_graph(graph):
-    with CAPTURE_LOCK:
+    with GPU_GUARD.exclusive():
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             yield
+
+
+def replay_graph(graph):
+    graph.replay()
 
 
 @contextlib.contextmanager

@@ -309,30 +309,42 @@ def test_corr_block_fast_is_differentiable(golden):
 # ---------------------------------------------------------------------------------
 @torch.no_grad()
 def test_two_threads_two_replicas_one_device():
+    """Two Python threads, two replicas sharing every sub-module (what nn.parallel.replicate hands to
+    parallel_apply), one device, a stream each: both capture and replay their own iteration graphs and both get
+    the single-threaded result bit for bit.  Inputs are on the device before the threads start (DataParallel
+    scatters first); a host synchronisation outside forward() holds the capture guard like forward() does."""
+    from dkt_stereo_amd.update import GPU_GUARD
     model, _ = _raft()
     replica = copy.copy(model)                       # what nn.parallel.replicate makes: shallow copies sharing
     replica._modules = dict(model._modules)          # parameters' storage and (here) every __dict__ entry
     pairs = [_synth.image_pair(s, 1, 64, 128, sh) for s, sh in ((0, 12), (5, 20))]
-    want = [model(G(a), G(b), iters=7, test_mode=True)[1].clone() for a, b in pairs]
+    dev_pairs = [(G(a), G(b)) for a, b in pairs]
+    want = [model(a, b, iters=7, test_mode=True)[1].clone() for a, b in dev_pairs]
     model._graph_state = None
-    out, err = [None, None], []
+    torch.cuda.synchronize()
+    for rounds in range(3):                          # three fresh rounds: the interleaving differs every time
+        out, err = [None, None], []
+        for m in (model, replica):
+            m._graph_state = None
 
-    def run(k, m):
-        try:
-            with torch.cuda.stream(torch.cuda.Stream()):
-                for _ in range(3):
-                    out[k] = m(G(pairs[k][0]), G(pairs[k][1]), iters=7, test_mode=True)[1].clone()
-                torch.cuda.current_stream().synchronize()
-        except Exception as e:        # noqa: BLE001
-            err.append(e)
+        def run(k, m):
+            try:
+                with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream()):
+                    m._graph_state = None            # this thread's state: capture again
+                    for _ in range(3):
+                        out[k] = m(dev_pairs[k][0], dev_pairs[k][1], iters=7, test_mode=True)[1].clone()
+                    with GPU_GUARD.shared():
+                        torch.cuda.current_stream().synchronize()
+            except Exception as e:        # noqa: BLE001
+                err.append(e)
 
-    th = [threading.Thread(target=run, args=(k, m)) for k, m in enumerate((model, replica))]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert not err, err
-    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+        th = [threading.Thread(target=run, args=(k, m)) for k, m in enumerate((model, replica))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not err, err
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
 
 
 # ---------------------------------------------------------------------------------

@@ -197,3 +197,44 @@ def test_evaluate_chain_on_cpu(tmp_path):
     # several samples: the evaluator averages per-image EPE but pools the outlier masks
     res2 = evaluate.validate(Fake(), [tuple(paths), (img1, img2, flow_gt, valid)], iters=3, device="cpu")
     assert abs(res2["epe"] - res["epe"]) < 1e-6 and res2["n"] == 2
+
+
+def test_capture_guard_excludes_other_forwards():
+    """update.GPU_GUARD: forwards hold it shared (concurrently), a capture upgrades to exclusive -- no other
+    thread is inside a forward while it runs -- and nothing deadlocks when several threads upgrade."""
+    import time
+    from dkt_stereo_amd.update import _CaptureGuard
+    g = _CaptureGuard()
+    inside, overlap, order = [0], [0], []
+    lock = threading.Lock()
+
+    def worker(i):
+        for _ in range(20):
+            with g.shared():
+                with lock:
+                    inside[0] += 1
+                with g.shared():                    # re-entrant
+                    pass
+                if i % 2 == 0:
+                    with lock:
+                        inside[0] -= 1              # hand the slot back for the upgrade, as exclusive() does
+                    with g.exclusive():
+                        with lock:
+                            if inside[0] != 0:
+                                overlap[0] += 1
+                            order.append(i)
+                        time.sleep(0.0005)
+                    with lock:
+                        inside[0] += 1
+                else:
+                    time.sleep(0.0002)
+                with lock:
+                    inside[0] -= 1
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join(timeout=60) for t in ts]
+    assert not any(t.is_alive() for t in ts), "deadlock"
+    assert overlap[0] == 0 and len(order) == 60
+    with g.exclusive():                             # also usable without holding it shared
+        pass
