@@ -15,6 +15,7 @@
 // HBM traffic per pixel: L*(K+1)*4 B of pyramid + 4 B of coordinate read, Cout*4 B written; the
 // lookup tensor never exists.
 #include "dkt_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 typedef float cf_f32x16 __attribute__((ext_vector_type(16)));
@@ -240,6 +241,147 @@ static int cf_launch(const CorrFeatArgs &a, int B, hipStream_t st) {
     return dkt_launch_status();
 }
 
+// Four-level form (L = 4, the RAFT-Stereo default): one wave = a 16-pixel segment, lane l: pixel l & 15, and the
+// FOUR quarter-waves g = l >> 4 take one level each -- 10 window loads and 9 taps per lane, 3 600 waves for
+// 1 024 SIMDs at 1/4 KITTI (the stand-alone lookup's parallelism; the 32-pixel form has half of it and twice the
+// dependent chain per lane).  MFMA: v_mfma_f32_16x16x4_f32, whose B fragment is lane l -> B[k = l >> 4][n = l & 15]:
+// step s multiplies tap s of the four levels.  MT = ceil(Cout / 16) accumulator tiles of 4 registers.
+typedef float cf_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int R, int MT>
+__global__ __launch_bounds__(256) void corr_feat16_kernel(CorrFeatArgs a) {
+    constexpr int K = 2 * R + 1;
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, g = lane >> 4;
+    const long gw = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const long hrow = gw / a.nseg;
+    if (hrow >= a.H) return;                  // wave-uniform
+    const int seg0 = (int)(gw - hrow * a.nseg) * 16;
+    const int w1 = seg0 + li;
+    const bool live = w1 < a.W1;
+    const int w1c = live ? w1 : a.W1 - 1;
+    const int b = blockIdx.y;
+    const long p = hrow * a.W1 + w1c;
+    const float cx = a.coords_x[(size_t)b * a.coords_bstride + p];
+
+    // ---- weights (k-major: wt[k][co]): A fragment of step s, tile m = W[co = 16m + li][k = g*K + s]
+    float A[MT][K];
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co = 16 * m + li;
+            const bool ok = co < a.Cout;
+            const float wv = a.w[(long)(g * K + s) * a.Cout + (ok ? co : 0)];
+            A[m][s] = ok ? wv : 0.0f;
+        }
+    float bv[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[m][r] = 0.0f;
+    if (a.bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * m + 4 * g + r;
+                bv[m][r] = a.bias[co < a.Cout ? co : a.Cout - 1];
+            }
+    }
+
+    // ---- the lookup of level g (selected among the four argument slots without a memory-indexed load)
+    const int lv = g;
+    const int wi = a.W2 >> lv;
+    const int qm = (w1c >> lv) % wi;
+    const float *lvl = g == 0 ? a.skew.p[0] : g == 1 ? a.skew.p[1] : g == 2 ? a.skew.p[2] : a.skew.p[3];
+    const float inv = g == 0 ? a.inv_wm1[0] : g == 1 ? a.inv_wm1[1] : g == 2 ? a.inv_wm1[2] : a.inv_wm1[3];
+    const float *base = lvl + (((long)b * a.H + hrow) * wi) * (long)a.pitch + w1c;
+    const float xc = __fdiv_rn(cx, (float)(1 << lv));
+    const float wm1 = (float)(wi - 1);
+    const float hwm1 = __fdiv_rn(wm1, 2.0f);
+    DktTap taps[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) taps[k] = cf_tap(__fadd_rn((float)(k - R), xc), wm1, inv, hwm1);
+    const int i0 = cf_clamp_idx(taps[0].fl, wi);
+    float win[K + 1];
+#pragma unroll
+    for (int t = 0; t <= K; ++t) {
+        const int c = i0 + t;
+        const bool in = c >= 0 && c < wi;
+        int sidx = (in ? c : 0) - qm;
+        if (sidx < 0) sidx += wi;
+        const float x = base[(long)sidx * a.pitch];
+        win[t] = in ? x : 0.0f;
+    }
+    bool odd = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) odd |= cf_clamp_idx(taps[k].fl, wi) != i0 + k;
+    float v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = dkt_blend(win[k], win[k + 1], taps[k]);
+    if (__any(odd)) {                         // rare (non-finite coordinates): re-sample the irregular taps one by one
+        auto at = [&](int c) -> float {
+            if (c < 0 || c >= wi) return 0.0f;
+            int sidx = c - qm;
+            if (sidx < 0) sidx += wi;
+            return base[(long)sidx * a.pitch];
+        };
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int ik = cf_clamp_idx(taps[k].fl, wi);
+            if (ik != i0 + k) v[k] = dkt_blend(at(ik), at(ik + 1), taps[k]);
+        }
+    }
+    if (a.tap && live) {
+        float *t = a.tap + (size_t)b * a.tap_bstride + p;
+#pragma unroll
+        for (int k = 0; k < K; ++k) t[(size_t)(g * K + k) * a.HW] = v[k];
+    }
+
+    // ---- 1x1 convolution on the exact-fp32 matrix pipe: D[co][px] += W[co][level g, tap s] * v_g[s][px]
+    cf_f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[m][r] = 0.0f;
+            asm volatile("" ::"v"(bv[m][r]));      // biases resident before the epilogue
+        }
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][s], v[s], acc[m], 0, 0, 0);
+
+    // ---- epilogue: C/D map of the 16x16 form: col = l & 15 (pixel), row = 4 (l >> 4) + r
+    float *ob = a.out + (size_t)b * a.out_bstride + hrow * a.W1 + w1c;
+    const bool full = 16 * MT <= a.Cout && seg0 + 16 <= a.W1;      // wave-uniform: no guards needed
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 16 * m + 4 * g + r;
+            float y = __fadd_rn(acc[m][r], bv[m][r]);
+            if (a.relu) y = dkt_relu(y);
+            if (full || (co < a.Cout && live)) ob[(size_t)co * a.HW] = y;
+        }
+}
+
+template <int R>
+static int cf16_launch(CorrFeatArgs a, int B, hipStream_t st) {
+    a.nseg = (a.W1 + 15) / 16;
+    const long waves = (long)a.H * a.nseg;
+    dim3 grid((unsigned)((waves + 3) / 4), (unsigned)B);
+    switch ((a.Cout + 15) / 16) {
+        case 1: hipLaunchKernelGGL((corr_feat16_kernel<R, 1>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((corr_feat16_kernel<R, 2>), grid, dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((corr_feat16_kernel<R, 3>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((corr_feat16_kernel<R, 4>), grid, dim3(256), 0, st, a); break;
+    }
+    return dkt_launch_status();
+}
+
 extern "C" int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *coords_x, long coords_bstride,
                                          const float *weight, const float *bias, float *out, long out_bstride,
                                          float *tap, long tap_bstride,
@@ -274,6 +416,9 @@ extern "C" int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *
     a.relu = relu ? 1 : 0;
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
+    // four levels: the 16-pixel form (one level per quarter-wave); DKT_CORR_FEAT_PX=32 forces the half-wave form
+    static const bool px32 = [] { const char *e = getenv("DKT_CORR_FEAT_PX"); return e && atoi(e) == 32; }();
+    if (L == 4 && !px32) return r == 4 ? cf16_launch<4>(a, B, st) : cf16_launch<3>(a, B, st);
     if (r == 4) {
         if (L == 4) return cf_launch<4, 4>(a, B, st);
         if (L == 3) return cf_launch<3, 4>(a, B, st);
