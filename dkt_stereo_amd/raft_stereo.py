@@ -25,7 +25,8 @@ from . import _ffi
 from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
 from .extractor import BasicEncoder, MultiBasicEncoder
-from .update import FUSE_GATES, BasicMultiUpdateBlock, _side_stream, GPU_GUARD, capture_graph, harness, interp, pool2x, replay_graph
+from .update import (FUSE_GATES, GPU_GUARD, BasicMultiUpdateBlock, _side_stream, capture_graph, gru_pair, harness, interp,
+                     pool2x, replay_graph)
 from . import conv as _conv
 from .utils import coords_grid
 
@@ -260,6 +261,86 @@ class RAFTStereo(nn.Module):
                 dst.copy_(src)
         return up_mask
 
+    #: rotated software pipeline (DKT_ROTATE=0: the schedule of _one_iteration_pipelined).  The captured unit is
+    #: not "iteration i" but  { gru16(i) on the side stream  ||  flow head(i-1), lookup(i), motion encoder(i) } ->
+    #: gru08(i) + gru32(i+1) : the middle GRU of an iteration only needs the finest state of the PREVIOUS one, so
+    #: it runs beside the previous iteration's flow head instead of in front of this iteration's finest GRU
+    #: (trace: gru08 waited ~100 us per iteration for the gru16 chain).  Same operations on the same operands in
+    #: an order the reference's data dependencies allow: bit-identical.
+    rotate = os.environ.get("DKT_ROTATE", "1") != "0"
+
+    def _stage_mid(self, nets, inp, hold):
+        """gru16 of the coming iteration + the two resampled copies of its result the other GRUs consume."""
+        self.update_block(nets, inp, iter32=False, iter16=True, iter08=False, update=False)
+        hold["up16"] = interp(nets[1], nets[0])          # gru08's operand (core/update.py:127)
+        hold["pool16"] = pool2x(nets[1])                 # gru32's operand (core/update.py:119)
+
+    def _stage_motion(self, corr_fn, coords0, coords1):
+        enc = self.update_block.encoder
+        corr = self._lookup(corr_fn, coords1)
+        if hasattr(corr, "materialize"):
+            corr = _Precomputed(enc._cor1(corr))
+        return enc(coords1 - coords0, corr)
+
+    def _stage_fine(self, nets, inp, mf, hold):
+        """gru08 of this iteration and gru32 of the next one in shared launches (update.gru_pair)."""
+        ub = self.update_block
+        nets[0], nets[2] = gru_pair(ub.gru08, (nets[0], *inp[0], [mf, hold["up16"]], nets[0]),
+                                    ub.gru32, (nets[2], *inp[2], [hold["pool16"]], nets[2]))
+
+    def _stage_head(self, nets, coords1, need_mask):
+        ub = self.update_block
+        delta_flow = ub.flow_head(nets[0])
+        mask = None
+        if need_mask:
+            mask = .25 * conv2d(conv2d(nets[0], ub.mask[0], relu=True), ub.mask[2])
+        coords1[:, :1].add_(delta_flow[:, :1])           # stereo: only x moves (raft_stereo.py:165-168)
+        return mask
+
+    def _rotated_unit(self, st):
+        """flow head(i-1), lookup + motion encoder(i)  ||  gru16(i)   ->   gru08(i) + gru32(i+1)."""
+        dev = st["coords1"].device
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        nets, hold = st["net"], {}
+        done = torch.cuda.Event()
+        with harness(inplace_state=True, side_stream=False):
+            side.wait_stream(main)                       # fork
+            with torch.cuda.stream(side):
+                self._stage_mid(nets, st["inp"], hold)
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in hold.values():
+                        t.record_stream(main)
+                done.record(side)
+            self._stage_head(nets, st["coords1"], False)
+            mf = self._stage_motion(st["corr"], st["coords0"], st["coords1"])
+            main.wait_event(done)                        # join
+            main.wait_stream(side)
+            self._stage_fine(nets, st["inp"], mf, hold)
+
+    def _iterate_rotated(self, st, iters):
+        """Prologue: gru32(0), gru16(0), lookup + motion encoder(0), gru08(0) + gru32(1).  Then iters-1 rotated
+        units (the first eagerly, one captured, the rest replayed), then the last flow head with the mask."""
+        nets, hold = st["net"], {}
+        with harness(inplace_state=True, side_stream=False):
+            self.update_block(nets, st["inp"], iter32=True, iter16=False, iter08=False, update=False)
+            self._stage_mid(nets, st["inp"], hold)
+            mf = self._stage_motion(st["corr"], st["coords0"], st["coords1"])
+            self._stage_fine(nets, st["inp"], mf, hold)
+        done = 0
+        if st["graph"] is None:
+            self._rotated_unit(st)           # eager once: packs weights, sizes the allocator
+            done = 1
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with capture_graph(g):
+                self._rotated_unit(st)
+            st["graph"] = g
+        for _ in range(iters - 1 - done):
+            replay_graph(st["graph"])
+        with harness(inplace_state=True, side_stream=False):
+            return self._stage_head(nets, st["coords1"], True)
+
     def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init):
         """Same arithmetic as the eager loop; iterations 2..iters-1 are replays of one
         captured HIP graph (~60 launches per iteration leave the CPU out of the loop)."""
@@ -269,7 +350,7 @@ class RAFTStereo(nn.Module):
         # weights and the biases, all of which are re-created when a parameter is replaced or written
         # (load_state_dict, .to(), optimiser steps) or the conv backend changes: those are part of the key.
         key = (fmap1.device, tuple(fmap1.shape), tuple(fmap2.shape), args.corr_implementation,
-               self._weights_fingerprint())
+               self._weights_fingerprint(), self.rotate, self.pair_grus, self.pipeline_grus, self.fuse_lookup)
         st = self._graph_state
         if st is None or st["key"] != key:
             st = dict(key=key, graph=None)
@@ -290,6 +371,10 @@ class RAFTStereo(nn.Module):
                     dst.copy_(src)
         if flow_init is not None:
             st["coords1"].add_(flow_init)
+        if self._can_pipeline() and self.rotate and self.pair_grus:
+            up_mask = self._iterate_rotated(st, iters)
+            flow = st["coords1"] - st["coords0"]
+            return flow, self.upsample_flow(flow, up_mask)[:, :1]
         if self._can_pipeline():
             # prologue: gru32 of iteration 0 (the reference runs it first in every iteration)
             with harness(inplace_state=True):
