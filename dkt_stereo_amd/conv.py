@@ -39,7 +39,10 @@ import torch.nn.functional as F
 
 from . import _ffi
 
+import os as _os
+
 _PASSES = {"f16x3": 3, "f16x2": 2, "f16": 1}
+_FEW_DIRECT = _os.environ.get("DKT_FEW_DIRECT", "1") != "0"
 _BACKEND = "f16x3"
 _TLS = threading.local()
 _CACHE_LOCK = threading.RLock()
@@ -215,6 +218,18 @@ def direct_eligible(layer):
     if kh != kw or pad != (kh // 2, kw // 2) or _stride_of(layer) != (1, 1):
         return False
     return kh == 7 and cin <= 4
+
+
+def few_eligible(layer):
+    """3x3, stride 1, padding 1, at most 4 output channels (flow_head.conv2 256 -> 2, disp_head.conv2 256 -> 1):
+    an HBM-bound layer that runs on the exact-fp32 DMA-staged kernel (dkt_conv2d_direct) instead of padding its
+    outputs to a 32-channel matrix-core tile.  DKT_FEW_DIRECT=0 sends it back to dkt_conv2d_f16s."""
+    if get_backend() not in _PASSES or not _plain_conv(layer) or not _FEW_DIRECT:
+        return False
+    cout, cin, kh, kw = layer.weight.shape
+    pad = layer.padding
+    pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+    return kh == 3 and kw == 3 and pad == (1, 1) and _stride_of(layer) == (1, 1) and cout <= 4
 
 
 def _conv2d_direct(x, layer, relu, out):
@@ -401,6 +416,8 @@ def conv2d(x, layer, relu=False, out=None):
         x = x[0]
     if direct_eligible(layer) and not isinstance(x, (list, tuple)):
         return _conv2d_stem7(x, layer, relu, out)
+    if few_eligible(layer) and not isinstance(x, (list, tuple)):
+        return _conv2d_direct(x, layer, relu, out)
     if not hip_eligible(layer):
         y = _vendor(x, layer, relu)
         if out is not None:

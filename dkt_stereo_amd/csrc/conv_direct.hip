@@ -7,6 +7,7 @@
 // Exact fp32 FMAs on the VALU (no operand splitting), accumulated in (channel, row, column) tap
 // order; the input patch of a channel chunk and its weights are staged in LDS.  Optional fused ReLU.
 #include "dkt_common.h"
+#include <cstdlib>
 
 struct DirectArgs {
     const float *x;
@@ -119,6 +120,172 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(DirectArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 convolution with very few output channels (flow_head.conv2 256 -> 2, disp_head.conv2 256 -> 1): the
+// layer is a 58.8 MB read for 0.5 GFLOP -- HBM-bound -- and the per-iteration tail of the update operator.
+//   block  = one 4-row x 64-column output tile (230 blocks at 184 x 312: every CU gets one), FEW_NW = 8 waves;
+//   wave w = input channels [w*Cin/8, (w+1)*Cin/8) in chunks of FEW_CC, lane = 4 adjacent pixels of one row;
+//   patch  = (4+2) rows x 72 columns per channel (image columns w0-4 .. w0+67: 16-byte groups), copied global ->
+//            LDS by the DMA path (global_load_lds_dwordx4: no registers, no VALU; a patch row is 18 lanes, so two
+//            instructions move a channel's 6 rows; W % 4 != 0 falls back to 4-byte pieces), double-buffered and
+//            WAVE-PRIVATE: no block barrier in the channel loop.  Cells outside the image are zero-filled once
+//            and never written again (their lanes are masked off);
+//   math   = exact fp32 FMAs; the wave's weights sit in LDS (staged once) and are read as broadcasts; a patch row
+//            is one 16-byte and two 4-byte LDS reads per lane;
+//   the eight channel slices are summed through LDS in wave order, bias / ReLU in the epilogue.
+// ---------------------------------------------------------------------------------------------------------
+#define FEW_CC 4
+#define FEW_NW 8                                    // waves per block = channel slices
+#define FEW_PR 6
+#define FEW_PCP 72                                   // patch row: image columns w0-4 .. w0+67 (16-byte aligned groups)
+template <int TO>
+__global__ __launch_bounds__(64 * FEW_NW) void conv3x3_few_kernel(DirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float few_lds[];   // [FEW_NW waves][2][FEW_CC][FEW_PR][FEW_PCP] + weights
+    constexpr int PLANE = FEW_PR * FEW_PCP, BUF = FEW_CC * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w0 = (blockIdx.x % a.tiles_w) * 64, h0 = (blockIdx.x / a.tiles_w) * 4;
+    const int b = blockIdx.z;
+    const long HW = (long)a.H * a.W;
+    const float *xb = a.x + (long)b * a.x_bs;
+    float *mybuf = few_lds + wave * 2 * BUF;
+    // zero both buffers once: cells outside the image are never written by the DMA below
+    for (int i = lane; i < 2 * BUF / 4; i += 64) ((float4 *)mybuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cq = (a.Cin + FEW_NW - 1) / FEW_NW;
+    const int c_lo = wave * cq, c_hi = min(a.Cin, c_lo + cq);
+    // this wave's weights -> LDS once ([channel][o][12]: 9 taps padded to three 16-byte groups), read back as broadcasts
+    float *wl = few_lds + FEW_NW * 2 * BUF + wave * cq * TO * 12;
+    for (int i = lane; i < (c_hi - c_lo) * TO * 9; i += 64) {
+        const int t = i % 9, o = (i / 9) % TO, c = i / (9 * TO);
+        wl[(c * TO + o) * 12 + t] = o < a.Cout ? a.w[((long)o * a.Cin + c_lo + c) * 9 + t] : 0.0f;
+    }
+    const int nchunk = (c_hi - c_lo + FEW_CC - 1) / FEW_CC;
+    // DMA of one chunk.  LDS destination of a DMA instruction = wave-uniform base + lane * size.
+    //   VEC (W % 4 == 0, 16-byte aligned planes): lane l of instruction j covers the 16-byte group g = 64 j + l of
+    //   the channel's 6 x 18 groups: patch row g / 18, columns 4 (g % 18) .. +3  -- two instructions per channel;
+    //   otherwise: per patch row one 64-lane and one 8-lane instruction of 4 bytes per lane.
+    const bool vec = (a.W & 3) == 0 && (((uintptr_t)a.x | (uintptr_t)(a.x_bs * 4)) & 15) == 0;
+    int g_row[2], g_off[2];
+    bool g_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = 64 * j + lane;
+        const int r = g / 18, c4 = 4 * (g - 18 * r);
+        const int ih = h0 - 1 + r, iw = w0 - 4 + c4;
+        g_ok[j] = g < FEW_PR * 18 && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;      // W % 4 == 0: a group is all in or all out
+        g_row[j] = r;
+        g_off[j] = g_ok[j] ? ih * a.W + iw : 0;
+    }
+    const int iw_a = w0 - 4 + lane, iw_b = w0 + 60 + lane;
+    const bool col_a = iw_a >= 0 && iw_a < a.W, col_b = lane < 8 && iw_b < a.W;
+    auto stage = [&](int chunk, int which) {
+        float *dst = mybuf + which * BUF;
+#pragma unroll
+        for (int c = 0; c < FEW_CC; ++c) {
+            const int ch = c_lo + chunk * FEW_CC + c;
+            if (ch >= c_hi) break;                                   // wave-uniform
+            const float *xc = xb + (long)ch * HW;
+            if (vec) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (g_ok[j])
+                        __builtin_amdgcn_global_load_lds(xc + g_off[j], (__attribute__((address_space(3))) void *)(dst + c * PLANE + 256 * j), 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < FEW_PR; ++r) {
+                    const int ih = h0 - 1 + r;
+                    if (ih < 0 || ih >= a.H) continue;               // wave-uniform: the row stays zero
+                    const float *row = xc + (long)ih * a.W;
+                    float *lrow = dst + c * PLANE + r * FEW_PCP;
+                    if (col_a) __builtin_amdgcn_global_load_lds(row + iw_a, (__attribute__((address_space(3))) void *)lrow, 4, 0, 0);
+                    if (col_b) __builtin_amdgcn_global_load_lds(row + iw_b, (__attribute__((address_space(3))) void *)(lrow + 64), 4, 0, 0);
+                }
+            }
+        }
+    };
+    const int prow = lane >> 4, q4 = 4 * (lane & 15);                // this lane's output row and first column
+    float acc[4][TO];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < TO; ++o) acc[p][o] = 0.0f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero fill has landed before the first DMA
+    if (nchunk > 0) stage(0, 0);
+    for (int k = 0; k < nchunk; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // chunk k is in LDS
+        if (k + 1 < nchunk) stage(k + 1, (k + 1) & 1);             // chunk k+1 streams in under the FMAs of chunk k
+        const float *src = mybuf + (k & 1) * BUF;
+#pragma unroll
+        for (int c = 0; c < FEW_CC; ++c) {
+            const int ch = c_lo + k * FEW_CC + c;
+            if (ch >= c_hi) break;                                   // wave-uniform
+            float wv[TO][12];                                        // same address in every lane: LDS broadcast reads
+#pragma unroll
+            for (int o = 0; o < TO; ++o) {
+                const float4 *wp = (const float4 *)(wl + ((ch - c_lo) * TO + o) * 12);
+                const float4 w0_ = wp[0], w1_ = wp[1], w2_ = wp[2];
+                wv[o][0] = w0_.x; wv[o][1] = w0_.y; wv[o][2] = w0_.z; wv[o][3] = w0_.w;
+                wv[o][4] = w1_.x; wv[o][5] = w1_.y; wv[o][6] = w1_.z; wv[o][7] = w1_.w;
+                wv[o][8] = w2_.x;
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                // image columns q4-1 .. q4+4 of the tile = patch columns q4+3 .. q4+8
+                const float *pr = src + c * PLANE + (prow + dy) * FEW_PCP + q4 + 4;
+                const float4 v4 = *(const float4 *)pr;
+                const float v[6] = {pr[-1], v4.x, v4.y, v4.z, v4.w, pr[4]};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int o = 0; o < TO; ++o) acc[p][o] = __fmaf_rn(v[p + dx], wv[o][dy * 3 + dx], acc[p][o]);
+            }
+        }
+    }
+    // ---- sum the four channel quarters (wave order), bias, ReLU, store
+    __syncthreads();
+    float *part = few_lds;                                           // [FEW_NW waves][TO][4 px][64 lanes]
+#pragma unroll
+    for (int o = 0; o < TO; ++o)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) part[((wave * TO + o) * 4 + p) * 64 + lane] = acc[p][o];
+    __syncthreads();
+    if (wave != 0) return;
+    const int oh = h0 + prow;
+    if (oh >= a.H) return;
+#pragma unroll
+    for (int o = 0; o < TO; ++o) {
+        if (o >= a.Cout) break;
+        const float bias = a.bias ? a.bias[o] : 0.0f;
+        float *yr = a.y + (long)b * a.y_bs + (long)o * HW + (long)oh * a.W + w0 + q4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (w0 + q4 + p >= a.W) continue;
+            float v = part[((0 * TO + o) * 4 + p) * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < FEW_NW; ++ww) v = __fadd_rn(v, part[((ww * TO + o) * 4 + p) * 64 + lane]);
+            v = __fadd_rn(v, bias);
+            if (a.relu) v = dkt_relu(v);
+            yr[p] = v;
+        }
+    }
+}
+
+template <int TO>
+static int launch_few(DirectArgs a, int B, hipStream_t st) {
+    const int cq = (a.Cin + FEW_NW - 1) / FEW_NW;
+    const size_t lds = ((size_t)FEW_NW * 2 * FEW_CC * FEW_PR * FEW_PCP + (size_t)FEW_NW * cq * TO * 12) * sizeof(float);
+    if (lds > 160 * 1024) return DKT_E_UNSUPPORTED;
+    auto kern = conv3x3_few_kernel<TO>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    a.tiles_w = (a.W + 63) / 64;
+    dim3 grid((unsigned)(a.tiles_w * ((a.H + 3) / 4)), 1, (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * FEW_NW), lds, st, a);
+    return dkt_launch_status();
+}
+
 template <int KS, int TO, int CC>
 static int launch_direct(const DirectArgs &a, int B, hipStream_t st) {
     const int tiles_h = (a.H + 15) / 16;
@@ -141,8 +308,11 @@ extern "C" int dkt_conv2d_direct(const float *x, long x_bstride, const float *w,
     hipStream_t st = (hipStream_t)stream;
     if (KH == 3) {
         if (Cout > 4) return DKT_E_UNSUPPORTED;       // wide layers belong to dkt_conv2d_f16s
-        if (Cout <= 2) return launch_direct<3, 2, 8>(a, B, st);
-        return launch_direct<3, 4, 8>(a, B, st);
+        static const bool old = [] { const char *e = getenv("DKT_DIRECT_LEGACY"); return e && atoi(e) != 0; }();
+        if (old) return Cout <= 2 ? launch_direct<3, 2, 8>(a, B, st) : launch_direct<3, 4, 8>(a, B, st);
+        if (Cout <= 1) return launch_few<1>(a, B, st);
+        if (Cout <= 2) return launch_few<2>(a, B, st);
+        return launch_few<4>(a, B, st);
     }
     if (Cin > 4) return DKT_E_UNSUPPORTED;
     return launch_direct<7, 16, 2>(a, B, st);

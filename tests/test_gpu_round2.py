@@ -514,3 +514,33 @@ def test_evaluation_chain_matches_reference(golden, tmp_path):
     val = disp > 0
     assert abs(res["epe"] - err[val].mean()) <= 1e-4
     assert abs(res["d1"] - 100.0 * (err[val] > 3.0).mean()) <= 1e-9
+
+
+# ---------------------------------------------------------------------------------
+# few-output 3x3 layers (flow head / disparity head tail) on the DMA-staged exact-fp32 kernel
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [("flow_head", 1, 256, 2, 184, 312, False), ("disp_head", 2, 256, 1, 33, 70, False),
+                                   ("odd", 1, 37, 3, 9, 130, True), ("c4", 3, 40, 4, 8, 8, True), ("one_px", 1, 5, 2, 1, 1, False),
+                                   ("narrow", 1, 256, 2, 5, 3, False)], ids=lambda s: s[0])
+@torch.no_grad()
+def test_few_output_conv3x3(shape):
+    """conv2d routes 3x3 layers with <= 4 outputs to dkt_conv2d_direct's DMA-staged kernel: exact fp32 FMAs,
+    four channel quarters summed in a fixed order -- within fp32 round-off of an fp64 convolution, deterministic."""
+    from dkt_stereo_amd import conv
+    name, B, cin, cout, H, W, relu = shape
+    with conv.use_backend("f16x3"):
+        torch.manual_seed(4321)
+        layer = torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+        assert conv.few_eligible(layer)
+        x = G(_synth.normal((B, cin, H, W), 97, name, scale=2.0))
+        ref = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=1)
+        ref = ref.clamp_min(0) if relu else ref
+        got = conv.conv2d(x, layer, relu=relu)
+        tol = max(2e-6, 1.5e-7 * (cin * 9) ** 0.5)
+        assert got.shape == ref.shape
+        assert float((got.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+        assert torch.equal(got, conv.conv2d(x, layer, relu=relu))
+        # into a channel slice of a wider buffer (the out= form)
+        buf = torch.full((B, cout + 3, H, W), 7.0, device=DEV)
+        conv.conv2d(x, layer, relu=relu, out=buf[:, 1:1 + cout])
+        assert torch.equal(buf[:, 1:1 + cout], got) and float(buf[:, 0].min()) == 7.0 and float(buf[:, -1].max()) == 7.0
