@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
 import os, sys, torch
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
-from exp_iter import gtime
+from iteration_stages import gtime
 from dkt_stereo_amd import conv
 CASES = (("gru16.zr", 256, [128, 128, 128], 92, 156), ("gru16.q", 128, [128, 128, 128], 92, 156),
          ("gru32.zr", 256, [128, 128], 46, 78), ("gru32.q", 128, [128, 128], 46, 78),
