@@ -13,14 +13,14 @@ after it) -- every GRU sees the inputs the sequential order gives it, results ar
 plain loop.  The feature / 3-D aggregation networks that produce the inputs are not part of this
 library.
 """
+import os
 import weakref
 
 import torch
 
 from . import conv as _conv
-import os
-
-from .update import FUSE_GATES, _side_stream, GPU_GUARD, capture_graph, harness, interp, pool2x, replay_graph
+from .conv import conv2d
+from .update import FUSE_GATES, GPU_GUARD, _side_stream, capture_graph, gru_pair, harness, interp, pool2x, replay_graph
 
 #: the coarsest GRU of the next iteration shares the finest GRU's two launches (dkt_conv2d_f16s_pair)
 PAIR_GRUS = os.environ.get("DKT_PAIR_GRUS", "1") != "0"
@@ -83,6 +83,76 @@ def _body(ub, st, need_mask, last):
     return mask
 
 
+# ---- rotated schedule (as raft_stereo.RAFTStereo._iterate_rotated): the captured unit is
+#   { middle GRU (i) on the side stream  ||  disparity head (i-1), geometry lookup (i), motion encoder (i) }  ->
+#   finest GRU (i) + coarsest GRU (i+1) in shared launches
+# -- the middle GRU of an iteration needs the finest state of the PREVIOUS one only.  Opt-in here (DKT_ROTATE_IGEV=1):
+# measured no gain on the IGEV loop (32.4 ms either way at cfg3 -- its geometry lookup and 162-channel motion
+# encoder already cover the middle GRU), so the default stays the schedule of _body.
+ROTATE = os.environ.get("DKT_ROTATE_IGEV", "0") == "1"
+
+
+def _mid(ub, nets, inp, hold):
+    ub(nets, inp, iter04=False, iter08=True, iter16=False, update=False)
+    hold["up"] = interp(nets[1], nets[0])
+    hold["pool"] = pool2x(nets[1])
+
+
+def _fine(ub, nets, inp, mf, hold):
+    nets[0], nets[2] = gru_pair(ub.gru04, (nets[0], *inp[0], [mf, hold["up"]], nets[0]),
+                                ub.gru16, (nets[2], *inp[2], [hold["pool"]], nets[2]))
+
+
+def _head(ub, st, need_mask):
+    delta = ub.disp_head(st.net[0])
+    mask = conv2d(st.net[0], ub.mask_feat_4[0], relu=True) if need_mask else None
+    st.disp.add_(delta)
+    return mask
+
+
+def _rotated_unit(ub, st):
+    dev = st.disp.device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    hold = {}
+    done = torch.cuda.Event()
+    with harness(inplace_state=True, side_stream=False):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _mid(ub, st.net, st.inp, hold)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in hold.values():
+                    t.record_stream(main)
+            done.record(side)
+        _head(ub, st, False)
+        mf = ub.encoder(st.disp, st.geo_fn(st.disp, st.coords))
+        main.wait_event(done)
+        main.wait_stream(side)
+        _fine(ub, st.net, st.inp, mf, hold)
+
+
+def _iterate_rotated(ub, st, iters):
+    hold = {}
+    with harness(inplace_state=True, side_stream=False):
+        ub(st.net, st.inp, iter04=False, iter08=False, iter16=True, update=False)      # coarsest GRU (0)
+        _mid(ub, st.net, st.inp, hold)
+        mf = ub.encoder(st.disp, st.geo_fn(st.disp, st.coords))
+        _fine(ub, st.net, st.inp, mf, hold)
+    done = 0
+    if st.graph is None:
+        _rotated_unit(ub, st)                        # eager once: packs weights, sizes the allocator
+        done = 1
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with capture_graph(g):
+            _rotated_unit(ub, st)
+        st.graph = g
+    for _ in range(iters - 1 - done):
+        replay_graph(st.graph)
+    with harness(inplace_state=True, side_stream=False):
+        return _head(ub, st, True)
+
+
 def _fingerprint(update_block):
     """Everything a captured iteration holds pointers to through a cached derivative (packed weight
     images, merged z|r weights, biases): a changed parameter or backend must force a new capture."""
@@ -110,7 +180,7 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
     if not pipelined:
         return _plain(update_block, geo_fn, init_disp, coords, list(net_list), inp_list, iters)
     key = (init_disp.device, tuple(init_disp.shape), tuple(geo_fn._shape), geo_fn._w2, geo_fn.num_levels,
-           geo_fn.radius, _fingerprint(update_block))
+           geo_fn.radius, _fingerprint(update_block), ROTATE, PAIR_GRUS)
     st = cache.get("state") if cache is not None else None
     if st is None or st.key != key or st.ub() is not update_block:
         st = _State()
@@ -139,6 +209,9 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
             for dst, src in zip(ds, ss):
                 dst.copy_(src)
     ub = update_block
+    if ROTATE and PAIR_GRUS:
+        mask = _iterate_rotated(ub, st, iters)
+        return st.disp.clone(), mask, [t.clone() for t in st.net]
     with harness(inplace_state=True):                # prologue: coarsest GRU of iteration 0
         ub(list(st.net), st.inp, iter04=False, iter08=False, iter16=True, update=False)
     done = 0
