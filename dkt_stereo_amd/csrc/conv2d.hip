@@ -39,12 +39,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CONV_MAX_SRC 4
-// scheduling tunables (swept with tools/sweep_conv_variants.sh)
+// scheduling tunables (swept with tools/build_conv_variant.sh + tools/conv_ablation.py)
 #ifndef CONV_AR
 #define CONV_AR 3
 #endif
 #ifndef CONV_ABL
-#define CONV_ABL 0        // timing-only ablation builds (tools/sweep_conv_variants.sh); 0 in the product
+#define CONV_ABL 0        // timing-only ablation builds (tools/build_abl_variants.sh); 0 in the product
 #endif
 #ifndef CONV_MIN_BLOCKS
 #define CONV_MIN_BLOCKS 2    // blocks per CU the register budget is capped for (256 VGPRs)
