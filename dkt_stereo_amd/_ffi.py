@@ -28,12 +28,14 @@ class ConvDesc(ctypes.Structure):
                 ("Cout", ctypes.c_int), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("relu", ctypes.c_int),
                 ("epilogue", ctypes.c_int), ("e0", ctypes.c_void_p), ("e0_bstride", ctypes.c_long),
                 ("e1", ctypes.c_void_p), ("e1_bstride", ctypes.c_long), ("h", ctypes.c_void_p),
-                ("h_bstride", ctypes.c_long), ("out2", ctypes.c_void_p), ("out2_bstride", ctypes.c_long)]
+                ("h_bstride", ctypes.c_long), ("out2", ctypes.c_void_p), ("out2_bstride", ctypes.c_long),
+                ("in_norm", ctypes.c_void_p)]
 
 
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
     "dkt_conv2d_f16s_pair": [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _i, _i, _vp],
+    "dkt_conv2d_f16s_desc": [ctypes.POINTER(ConvDesc), _i, _i, _vp],
     "dkt_corr1d_build": [_vp, _vp, _pp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_corr1d_lookup": [_pp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_convex_upsample": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -64,6 +66,7 @@ SIGNATURES = {
                         _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_instance_norm_stats": [_vp, _vp, _i, _l, _i, _vp],
     "dkt_instance_norm_add_relu": [_vp, _vp, _vp, _vp, _i, _l, _f, _i, _vp],
+    "dkt_instance_norm_finalize": [_vp, _i, _l, _f, _vp, _i, _vp],
     "dkt_conv2d_stem7_packed_elems": [_i],
     "dkt_conv2d_stem7_pack": [_vp, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_stem7": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp],

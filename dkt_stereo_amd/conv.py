@@ -99,6 +99,11 @@ def calibrate(margin_bits=2):
             layer.dkt_in_exp = 0 if (-2 <= e <= 16 - margin_bits) else e
 
 
+def calibrating():
+    """True inside ``with calibrate():`` on this thread (range recording synchronises: no stream capture then)."""
+    return getattr(_TLS, "calib", None) is not None
+
+
 def _vendor(x, layer, relu):
     if isinstance(x, (list, tuple)):
         x = x[0] if len(x) == 1 else torch.cat(list(x), dim=1)
@@ -349,6 +354,40 @@ def _desc(op, out, relu=False, epilogue=0, e0=None, e1=None, h=None, out2=None):
             setattr(d, name + "_bstride", t.stride(0))
     d._keep = (op, out, e0, e1, h, out2)
     return d
+
+
+def fused_eligible(layer, in_norm=False):
+    """`layer` can take a residual operand (epilogue 3) and, with in_norm, the instance norm of its input in the
+    staging (dkt_conv2d_f16s_desc): stride 1, 1x1 / 3x3 on the split-fp16 kernel; in_norm: 3x3, 33..128 outputs."""
+    if not hip_eligible(layer) or _stride_of(layer) != (1, 1):
+        return False
+    cout, _, kh, _ = layer.weight.shape
+    return (kh == 3 and 32 < cout <= 128) if in_norm else True
+
+
+def conv2d_fused(x, layer, relu=False, residual=None, in_norm=None):
+    """One stride-1 convolution with the neighbouring streaming passes folded in (core/extractor.py:46-60):
+      in_norm : (B*Cin, 2) float (mean, 1/std) per input plane -> the layer reads relu((x - mean) * invstd);
+      residual: tensor shaped like the result -> relu(residual + [relu](conv(x) + bias)).
+    Bit-identical to the separate passes (same arithmetic, same order)."""
+    op = _Operands(x, layer)
+    out = torch.empty((op.B, op.cout, op.H, op.W), device=op.device, dtype=torch.float32)
+    if residual is not None:
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError("conv2d_fused: residual shape %s != result shape %s" % (tuple(residual.shape), tuple(out.shape)))
+        residual = residual if _dense(residual) else residual.contiguous()
+        _ffi.require_gpu(residual)
+        _ffi.require_no_grad(residual)
+    d = _desc(op, out, relu=relu, epilogue=3 if residual is not None else 0, e0=residual)
+    if in_norm is not None:
+        if op.n != 1 or in_norm.dtype != torch.float32 or in_norm.numel() != 2 * op.B * int(op.srcs[0].shape[1]):
+            raise ValueError("conv2d_fused: in_norm must hold (mean, 1/std) for every (batch, channel) plane of one operand")
+        in_norm = in_norm.contiguous()
+        d.in_norm = in_norm.data_ptr()
+        d._keep = d._keep + (in_norm,)
+    rc = _ffi.lib().dkt_conv2d_f16s_desc(ctypes.byref(d), op.passes, _ffi.device_of(out), _ffi.stream_of(out))
+    _ffi.check(rc, "dkt_conv2d_f16s_desc")
+    return out
 
 
 def pair_eligible(layer_a, layer_b):

@@ -92,6 +92,11 @@ struct ConvArgs {
     long e_c0_bs, e_c1_bs, e_h_bs;
     float *out2;
     long out2_bs;
+    //   3: residual join (core/extractor.py:60 with the preceding norm folded into the weights):
+    //      out = relu(e_c0 + [relu](v))
+    // Instance-norm of the INPUT folded into the staging (kernel instantiations with NRM = 1; one source):
+    // (mean, 1/std) per (batch, channel) plane; the kernel convolves relu((x - mean) * invstd).
+    const float *in_norm;
 };
 
 // Gate non-linearities for the fused epilogues.  The epilogue runs on the VALU after the
@@ -121,7 +126,7 @@ struct ConvArgsPair {
 
 // ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
 // the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2, int NRM = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) void conv2d_f16s_kernel(ConvArgsPair ap, int nb0) {
     // Two independent convolutions may share one launch (dkt_conv2d_f16s_pair): blocks [0, nb0) stream
     // the tiles of problem 0, the others those of problem 1 -- a small layer (the coarsest GRU: 36
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
     unsigned shw[SIT][4], slw[SIT][4];        // converted (hi, lo) fp16 pairs awaiting the LDS write
     const float *sbase = nullptr;             // plane of the first channel this wave stages (wave-uniform)
     int snch = 0;                             // valid channels from there on (<= 0: all padding)
+    float nmean[NRM ? 8 : 1], ninv[NRM ? 8 : 1];   // NRM: (mean, 1/std) of the 8 planes this wave stages (wave-uniform)
     auto stage_tile = [&](int th0, int tw0) {
 #pragma unroll
         for (int it = 0; it < SIT; ++it) {
@@ -215,6 +221,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
         const int cb = c0 + 8 * swave;
         snch = a.src_ch[s] - cb;
         sbase = a.src[s] + (long)tb * a.src_bs[s] + (long)(snch > 0 ? cb : 0) * HW;
+        if (NRM) {
+            const float *np = a.in_norm + 2 * ((long)tb * a.src_ch[0] + (snch > 0 ? cb : 0));
+#pragma unroll
+            for (int j = 0; j < (NRM ? 8 : 1); ++j) {
+                const int jc = min(j, max(snch, 1) - 1);
+                // wave-uniform values: pinned into SGPRs (the loads themselves are vector loads -- the compiler
+                // cannot prove the buffer is not written by this kernel -- and would otherwise hold 16 VGPRs)
+                nmean[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(np[2 * jc])));
+                ninv[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(np[2 * jc + 1])));
+            }
+        }
     };
     auto stage_load = [&](int k0, int k1) {
 #pragma unroll
@@ -238,8 +255,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
         for (int k = k0; k < k1; ++k) {
             if (k >= NSL) break;
             const int it = k >> 2, q = k & 3;
-            const float v0 = (2 * q < snch && sok[it]) ? sreg[it][2 * q] : 0.0f;
-            const float v1 = (2 * q + 1 < snch && sok[it]) ? sreg[it][2 * q + 1] : 0.0f;
+            float u0 = sreg[it][2 * q], u1 = sreg[it][2 * q + 1];
+            if (NRM) {     // the arithmetic of instnorm_apply_kernel (norm.hip), so that the fusion is bit-identical
+                u0 = dkt_relu(__fmul_rn(__fsub_rn(u0, nmean[(2 * q) % (NRM ? 8 : 1)]), ninv[(2 * q) % (NRM ? 8 : 1)]));
+                u1 = dkt_relu(__fmul_rn(__fsub_rn(u1, nmean[(2 * q + 1) % (NRM ? 8 : 1)]), ninv[(2 * q + 1) % (NRM ? 8 : 1)]));
+            }
+            const float v0 = (2 * q < snch && sok[it]) ? u0 : 0.0f;
+            const float v1 = (2 * q + 1 < snch && sok[it]) ? u1 : 0.0f;
             // range: |x * in_scale| must stay below 65520 (the fp16 hi part); beyond that -- and for
             // NaN / Inf inputs -- the result is non-finite, never a silently saturated value
             const float x0 = v0 * a.in_scale;
@@ -412,6 +434,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
                     if (a.epi == 1) {
                         const float g = conv_sigmoid(__fadd_rn(v, gc[i]));
                         po[o] = second ? __fmul_rn(g, gh[i]) : g;
+                    } else if (a.epi == 3) {
+                        po[o] = dkt_relu(__fadd_rn(gc[i], a.relu ? dkt_relu(v) : v));
                     } else {
                         const float q = conv_tanh(__fadd_rn(v, gc[i]));
                         po[o] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, gz[i]), gh[i]), __fmul_rn(gz[i], q));
@@ -593,12 +617,12 @@ struct ConvSecond {
     int B;
 };
 
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2>
+template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2, int NRM = 0>
 static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec = nullptr) {
     constexpr int NPP = ((NF * WN - 1) * ST + KS) * (31 * ST + KS);
     constexpr int STAGE = NPP * (8 * CK + 4) * (PASSES == 3 ? 2 : 1);
     const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);   // + dummy words for surplus staging lanes
-    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF, ST, CK>;
+    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF, ST, CK, NRM>;
     // once per device and instantiation (and never inside a stream capture after warm-up)
     static int slots[64] = {0};                        // benign race: worst case computed twice
     int dev = 0;
@@ -657,6 +681,23 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec 
 template <int KS, int PASSES>
 static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const ConvSecond *sec = nullptr) {
     const long tiles4 = (long)a.tiles_w * ((a.H + 3) / 4) * B;    // blocks if a block covers 4 rows
+    if (a.in_norm) {
+        // instance norm + ReLU of the input folded into the staging: the second 3x3 layer of the feature
+        // encoder's residual blocks (core/extractor.py:46-50; 64, 96 and 128 channels) -- the same tile
+        // shapes as below, instantiated with NRM = 1
+        if constexpr (KS == 3) {
+            if (sec || a.nsrc != 1 || a.epi == 1 || a.epi == 2) return DKT_E_UNSUPPORTED;
+            if (a.Cout > 32 && a.Cout <= 64) {
+                if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1, 1>(a, B, st);
+                return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 2, 1, 2, 1>(a, B, st);
+            }
+            if (a.Cout > 64 && a.Cout <= 128) {
+                if (tiles4 < CONV_FEW_TILES) return launch_conv<KS, 2, 2, 1, PASSES, CONV_ABL, 2, 1, 2, 1>(a, B, st);
+                return launch_conv<KS, 2, 2, 2, PASSES, CONV_ABL, 2, 1, 2, 1>(a, B, st);
+            }
+        }
+        return DKT_E_UNSUPPORTED;
+    }
     static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5|6|7|8 forces a tile shape
         const char *e = getenv("DKT_CONV_CFG");
         return e ? atoi(e) : 0;
@@ -724,7 +765,7 @@ int conv2d_launch_p3(const ConvArgs &a, int B, int KH, int stride, hipStream_t s
 template <int PASSES>
 static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) {
     if (stride == 2) {
-        if (sec) return DKT_E_UNSUPPORTED;
+        if (sec || a.in_norm) return DKT_E_UNSUPPORTED;
         if (KH == 3) return launch_conv_stride2<3, PASSES>(a, B, st);
         return launch_conv_stride2<1, PASSES>(a, B, st);
     }
@@ -790,6 +831,7 @@ static int conv_fill(ConvArgs &a, const float *const *src, const int *src_channe
     a.e_c0_bs = a.e_c1_bs = a.e_h_bs = 0;
     a.out2 = nullptr;
     a.out2_bs = 0;
+    a.in_norm = nullptr;
     if (epi) {
         a.epi = epi->kind;
         a.e_c0 = epi->c0; a.e_c1 = epi->c1; a.e_h = epi->h;
@@ -822,19 +864,37 @@ static int conv2d_f16s_impl(const float *const *src, const int *src_channels, co
 static int conv_fill_desc(ConvArgs &a, const dkt_conv_desc *d, int passes) {
     if (!d) return DKT_E_NULL;
     ConvEpilogue e = {d->epilogue, d->e0, d->e1, d->h, d->e0_bstride, d->e1_bstride, d->h_bstride, d->out2, d->out2_bstride};
-    if (d->epilogue < 0 || d->epilogue > 2) return DKT_E_UNSUPPORTED;
+    if (d->epilogue < 0 || d->epilogue > 3) return DKT_E_UNSUPPORTED;
     if (d->epilogue == 1) {
         if (!d->e0 || !d->e1 || !d->h || !d->out2) return DKT_E_NULL;
         if (d->Cout % 128 != 0) return DKT_E_UNSUPPORTED;          // Ch multiple of 64: z and r never share a wave
     } else if (d->epilogue == 2) {
         if (!d->e0 || !d->e1 || !d->h) return DKT_E_NULL;
+    } else if (d->epilogue == 3) {
+        if (!d->e0) return DKT_E_NULL;
     }
-    return conv_fill(a, d->src, d->src_channels, d->src_bstride, d->nsrc, d->w_hi, d->w_lo, d->bias, d->out_scale,
-                     d->in_scale, d->out, d->out_bstride, d->B, d->H, d->W, d->Cout, d->KH, d->KW, d->relu, passes,
-                     d->epilogue ? &e : nullptr, 1);
+    const int rc = conv_fill(a, d->src, d->src_channels, d->src_bstride, d->nsrc, d->w_hi, d->w_lo, d->bias, d->out_scale,
+                             d->in_scale, d->out, d->out_bstride, d->B, d->H, d->W, d->Cout, d->KH, d->KW,
+                             d->relu, passes,
+                             d->epilogue ? &e : nullptr, 1);
+    if (rc != DKT_OK) return rc;
+    if (d->in_norm) {
+        if (d->nsrc != 1 || d->KH != 3 || d->Cout <= 32 || d->Cout > 128 || d->epilogue == 1 || d->epilogue == 2)
+            return DKT_E_UNSUPPORTED;
+        a.in_norm = d->in_norm;
+    }
+    return DKT_OK;
 }
 
 static int conv_width_class(int Cout) { return Cout <= 32 ? 0 : Cout <= 64 ? 1 : Cout <= 128 ? 2 : 3; }
+
+extern "C" int dkt_conv2d_f16s_desc(const dkt_conv_desc *p, int passes, int device, void *stream) {
+    ConvArgs a;
+    const int rc = conv_fill_desc(a, p, passes);
+    if (rc != DKT_OK) return rc;
+    DKT_ENTER(device);
+    return conv_dispatch(a, p->B, p->KH, 1, passes, (hipStream_t)stream, nullptr);
+}
 
 extern "C" int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc *p1, int passes, int device, void *stream) {
     ConvArgs a;
@@ -843,6 +903,7 @@ extern "C" int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc
     if (rc != DKT_OK) return rc;
     rc = conv_fill_desc(sec.a, p1, passes);
     if (rc != DKT_OK) return rc;
+    if (p0->in_norm || p1->in_norm) return DKT_E_UNSUPPORTED;
     sec.B = p1->B;
     // both problems run one kernel instantiation: same filter size and the same output-width class
     if (p0->KH != p1->KH || conv_width_class(p0->Cout) != conv_width_class(p1->Cout)) return DKT_E_UNSUPPORTED;

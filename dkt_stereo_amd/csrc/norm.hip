@@ -123,6 +123,36 @@ extern "C" int dkt_instance_norm(const float *x, float *y, void *workspace, int 
     return dkt_launch_status();
 }
 
+// (mean, 1/std) per plane as two floats -- the form the convolution kernel's staging takes
+// (dkt_conv_desc.in_norm): the normalise(+ReLU) pass between two layers disappears.  Same
+// arithmetic as instnorm_apply_kernel's prologue.
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const double *__restrict__ part, float *__restrict__ out,
+                                                                int planes, long HW, int S, float eps) {
+    const int plane = blockIdx.x * 256 + threadIdx.x;
+    if (plane >= planes) return;
+    double sum = 0.0, sq = 0.0;
+    for (int s = 0; s < S; ++s) {
+        sum += part[((long)plane * S + s) * 2];
+        sq += part[((long)plane * S + s) * 2 + 1];
+    }
+    const double mean_d = sum / (double)HW;
+    double var_d = sq / (double)HW - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    out[2 * plane] = (float)mean_d;
+    out[2 * plane + 1] = 1.0f / sqrtf((float)var_d + eps);
+}
+
+extern "C" int dkt_instance_norm_finalize(const void *workspace, int planes, long HW, float eps, float *mean_invstd,
+                                          int device, void *stream) {
+    if (!workspace || !mean_invstd) return DKT_E_NULL;
+    if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const int S = instnorm_split(planes, HW);
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double *)workspace, mean_invstd, planes, HW, S, eps);
+    return dkt_launch_status();
+}
+
 // The tail of a residual block with instance norm (core/extractor.py:52-60) in one pass:
 //   y = relu(a + relu((c - mean_c) * invstd_c)),  statistics of c from dkt_instance_norm_stats.
 // Replaces the normalise(+ReLU) pass over c and the separate add+ReLU pass.

@@ -13,7 +13,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import _CACHE_LOCK, conv2d
+import os
+
+from .conv import _CACHE_LOCK, conv2d, conv2d_fused, fused_eligible
+
+#: DKT_FUSE_ENCODER=0: separate normalise / residual-join passes around the encoders' convolutions (A/B switch)
+FUSE_ENCODER = os.environ.get("DKT_FUSE_ENCODER", "1") != "0"
 
 
 def _hip_ok(x):
@@ -81,15 +86,35 @@ def _folded_locked(conv, bn):
     return f
 
 
+def _foldable(conv, norm, x):
+    return (isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats
+            and isinstance(conv, nn.Conv2d) and _hip_ok(x) and conv.padding_mode == 'zeros'
+            and not (torch.is_grad_enabled() and conv.weight.requires_grad))
+
+
 def conv_norm_act(conv, norm, x, relu):
     """norm(conv(x)) [+ ReLU].  An eval-mode BatchNorm (cnet: frozen statistics,
     raft_stereo.py:56-59) is folded into the convolution and the ReLU into its epilogue, which
     removes two full passes over the activation per layer; other norms go through norm_act."""
-    if (isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats
-            and isinstance(conv, nn.Conv2d) and _hip_ok(x) and conv.padding_mode == 'zeros'
-            and not (torch.is_grad_enabled() and conv.weight.requires_grad)):
+    if _foldable(conv, norm, x):
         return conv2d(x, _folded(conv, norm), relu=relu)      # conv2d honours f.stride
     return norm_act(norm, conv(x), relu)
+
+
+def instance_norm_params(norm, x):
+    """(N*C, 2) float tensor of (mean, 1/sqrt(var + eps)) per plane of x (dkt_instance_norm_stats +
+    dkt_instance_norm_finalize): the `in_norm` operand of conv.conv2d_fused."""
+    x = x if x.is_contiguous() else x.contiguous()
+    n, c, h, w = x.shape
+    L = _ffi.lib()
+    ws = torch.empty(L.dkt_instance_norm_workspace(n * c, h * w), device=x.device, dtype=torch.uint8)
+    out = torch.empty((n * c, 2), device=x.device, dtype=torch.float32)
+    rc = L.dkt_instance_norm_stats(x.data_ptr(), ws.data_ptr(), n * c, h * w, _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_instance_norm_stats")
+    rc = L.dkt_instance_norm_finalize(ws.data_ptr(), n * c, h * w, float(norm.eps), out.data_ptr(),
+                                      _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_instance_norm_finalize")
+    return out
 
 
 def _plain_instance_norm(norm):
@@ -166,11 +191,23 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(_Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
+        fuse = FUSE_ENCODER and _hip_ok(x)
+        if fuse and _plain_instance_norm(self.norm1) and _plain_instance_norm(self.norm2) and fused_eligible(self.conv2, True):
+            # fnet: relu(norm1(.)) between the two layers lives in conv2's staging (no normalise pass, the
+            # intermediate is read once for its statistics and once by conv2)
+            c1 = self.conv1(x)
+            if self.downsample is not None:
+                x = conv_norm_act(self.downsample[0], self.norm3, x, False)
+            c2 = conv2d_fused(c1, self.conv2, in_norm=instance_norm_params(self.norm1, c1))
+            return norm_add_relu(self.norm2, x, c2)
         y = conv_norm_act(self.conv1, self.norm1, x, True)
         if self.downsample is not None:
             x = conv_norm_act(self.downsample[0], self.norm3, x, False)
         if _plain_instance_norm(self.norm2):
             return norm_add_relu(self.norm2, x, self.conv2(y))      # norm2 + ReLU folded into the join
+        if (fuse and _foldable(self.conv2, self.norm2, y) and fused_eligible(self.conv2) and x.shape[1] == self.conv2.weight.shape[0]):
+            # cnet: norm2 folded into the weights, ReLU + residual join in the epilogue
+            return conv2d_fused(y, _folded(self.conv2, self.norm2), relu=True, residual=x)
         y = conv_norm_act(self.conv2, self.norm2, y, True)
         return add_relu(x, y)
 

@@ -28,6 +28,7 @@ from .extractor import BasicEncoder, MultiBasicEncoder
 from .update import (FUSE_GATES, GPU_GUARD, BasicMultiUpdateBlock, _side_stream, capture_graph, gru_pair, harness, interp,
                      pool2x, replay_graph)
 from . import conv as _conv
+from . import extractor as _extractor
 from .utils import coords_grid
 
 #: configs/raft_stereo/base.json of the reference
@@ -62,6 +63,7 @@ class _Precomputed:
 #: are neither picklable nor deep-copyable) and per thread (two threads driving one module each need
 #: their own static buffers and capture).
 _GRAPH_STATES = weakref.WeakKeyDictionary()
+_ENCODER_STATES = weakref.WeakKeyDictionary()      # same, for the captured encoder pass
 _GRAPH_LOCK = threading.Lock()
 
 
@@ -103,9 +105,57 @@ class RAFTStereo(nn.Module):
     #: run fnet and cnet on two HIP streams (DKT_ENCODER_STREAMS=0 disables)
     encoder_streams = os.environ.get("DKT_ENCODER_STREAMS", "1") != "0"
 
+    #: replay the encoder pass (normalisation, fnet || cnet, context split: ~110 launches, two streams) from a
+    #: captured HIP graph as well: launched eagerly, the host needs 2.5 ms to enqueue fnet before cnet's first
+    #: kernel can start, and ~0.3 ms of launch gaps precede the first convolution.  Opt-in (DKT_ENCODER_GRAPH=1): at
+    #: 736x1248 the encoders are GPU-bound and the replay measured no faster (9.63 vs 9.45 ms); it pays on small images
+    graph_encoders = os.environ.get("DKT_ENCODER_GRAPH", "0") == "1"
+
+    def _encoder_fingerprint(self):
+        fp = [(_conv.get_backend(), _extractor.FUSE_ENCODER, self.encoder_streams)]
+        for mod in (self.fnet, self.cnet, self.context_zqr_convs):
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                fp.append((t.data_ptr(), t._version))
+            for m in mod.modules():
+                e = getattr(m, "dkt_in_exp", None)
+                if e:
+                    fp.append(("in_exp", id(m), e))
+                if isinstance(m, nn.BatchNorm2d):
+                    fp.append(("bn", id(m), m.training))
+        return tuple(fp)
+
     # -- pieces of the reference forward, split so the hot path can be timed alone --
     def encode(self, image1, image2):
-        """raft_stereo.py:91-116: normalisation, encoders, context split."""
+        """raft_stereo.py:91-116: normalisation, encoders, context split.  With the captured graph the returned
+        tensors are the graph's static outputs: valid until the next encode() on this thread."""
+        if (self.use_hip_graph and self.graph_encoders and image1.is_cuda and image1.dtype == torch.float32
+                and image2.dtype == torch.float32 and image1.shape == image2.shape
+                and not torch.is_grad_enabled() and not _conv.calibrating()):
+            return self._encode_graphed(image1, image2)
+        return self._encode(image1, image2)
+
+    def _encode_graphed(self, image1, image2):
+        key = (image1.device, tuple(image1.shape), self.args.n_gru_layers, self._encoder_fingerprint())
+        tid = threading.get_ident()
+        with _GRAPH_LOCK:
+            st = _ENCODER_STATES.setdefault(self, {}).get(tid)
+        if st is None or st["key"] != key:
+            out = self._encode(image1, image2)      # eager once: packs weights, folds norms, sizes the allocator
+            torch.cuda.synchronize(image1.device)
+            st = dict(key=key, img1=image1.clone(), img2=image2.clone())
+            g = torch.cuda.CUDAGraph()
+            with capture_graph(g):
+                st["out"] = self._encode(st["img1"], st["img2"])
+            st["graph"] = g
+            with _GRAPH_LOCK:
+                _ENCODER_STATES.setdefault(self, {})[tid] = st
+            return out
+        st["img1"].copy_(image1)
+        st["img2"].copy_(image2)
+        replay_graph(st["graph"])
+        return st["out"]
+
+    def _encode(self, image1, image2):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         n = self.args.n_gru_layers

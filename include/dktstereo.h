@@ -321,8 +321,16 @@ typedef struct dkt_conv_desc {
     const float *e1; long e1_bstride;
     const float *h;  long h_bstride;
     float *out2;     long out2_bstride;
+    const float *in_norm;   /* optional, dkt_conv2d_f16s_desc only: (B*src_channels[0], 2) = (mean, 1/std) per input
+                             * plane; the layer convolves relu((x - mean) * invstd) instead of x (nsrc = 1, 3x3,
+                             * 32 < Cout <= 128).  NULL: plain input. */
 } dkt_conv_desc;
 int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc *p1, int passes, int device, void *stream);
+/* One stride-1 convolution given as a descriptor.  Besides the epilogues above:
+ *   epilogue 3: residual join of a residual block whose norm is folded into the weights
+ *               (core/extractor.py:52-60): out = relu(e0 + [ReLU](out_scale*acc + bias)), e0 shaped like out;
+ *   in_norm   : see the field. */
+int dkt_conv2d_f16s_desc(const dkt_conv_desc *p, int passes, int device, void *stream);
 
 /* The 7x7 stems (Cin <= 4, stride 1, padding 3: core/update.py:75, igev_stereo/update.py:81,
  * core/extractor.py:136) on the fp16 matrix cores with split operands (stem7.hip): K laid out
@@ -365,6 +373,11 @@ int dkt_instance_norm(const float *x, float *y, void *workspace, int planes, lon
 int dkt_instance_norm_stats(const float *x, void *workspace, int planes, long HW, int device, void *stream);
 int dkt_instance_norm_add_relu(const float *a, const float *c, float *y, const void *workspace,
                                int planes, long HW, float eps, int device, void *stream);
+/* The statistics of dkt_instance_norm_stats as (mean, 1/sqrt(var + eps)) float pairs, one per plane: the
+ * `in_norm` operand of dkt_conv2d_f16s_desc, which folds relu(instance_norm(x)) between the two 3x3 layers
+ * of a residual block (core/extractor.py:46-50) into the second layer's staging. */
+int dkt_instance_norm_finalize(const void *workspace, int planes, long HW, float eps, float *mean_invstd /* (planes,2) */,
+                               int device, void *stream);
 
 int dkt_add_relu(const float *a, const float *b, float *y, long n, int device, void *stream);
 

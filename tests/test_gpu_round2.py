@@ -544,3 +544,125 @@ def test_few_output_conv3x3(shape):
         buf = torch.full((B, cout + 3, H, W), 7.0, device=DEV)
         conv.conv2d(x, layer, relu=relu, out=buf[:, 1:1 + cout])
         assert torch.equal(buf[:, 1:1 + cout], got) and float(buf[:, 0].min()) == 7.0 and float(buf[:, -1].max()) == 7.0
+
+
+# ---------------------------------------------------------------------------------
+# encoder glue folded into the convolutions (dkt_conv2d_f16s_desc: in_norm, epilogue 3)
+# ---------------------------------------------------------------------------------
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [("c64_small", 2, 64, 40, 72), ("c64_full", 1, 64, 128, 1024),
+                                   ("c96_small", 2, 96, 24, 60), ("c128_mid", 1, 128, 64, 500)], ids=lambda s: s[0])
+def test_conv_in_norm_fused_is_bit_identical(shape):
+    """relu(instance_norm(x)) folded into the staging of the following 3x3 layer (core/extractor.py:46-50) gives the
+    bits of the separate normalise pass + convolution -- in every tile shape the fused form is instantiated for."""
+    from dkt_stereo_amd import conv, extractor
+    name, B, C, H, W = shape
+    with conv.use_backend("f16x3"):
+        torch.manual_seed(77)
+        layer = torch.nn.Conv2d(C, C, 3, padding=1).to(DEV)
+        norm = torch.nn.InstanceNorm2d(C)
+        x = G(_synth.normal((B, C, H, W), 41, name, scale=3.0)) + 0.7
+        assert conv.fused_eligible(layer, True)
+        params = extractor.instance_norm_params(norm, x)
+        ref_n = F.instance_norm(x.double())
+        assert float((params[:, 0].double() - x.double().mean((2, 3)).reshape(-1)).abs().max()) < 1e-5
+        want = conv.conv2d(extractor.norm_act(norm, x, True), layer)
+        got = conv.conv2d_fused(x, layer, in_norm=params)
+        assert torch.equal(got, want)
+        ref = F.conv2d(ref_n.clamp_min(0), layer.weight.double(), layer.bias.double(), padding=1)
+        assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        # with the residual join on top
+        res = G(_synth.normal((B, C, H, W), 42, name))
+        got = conv.conv2d_fused(x, layer, relu=True, in_norm=params, residual=res)
+        assert torch.equal(got, extractor.add_relu(res, want.clamp_min(0)))
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [("3x3_64", 2, 64, 64, 3, 40, 72), ("3x3_128_mid", 1, 96, 128, 3, 64, 500),
+                                   ("3x3_256", 1, 128, 256, 3, 46, 78), ("1x1_128", 2, 128, 128, 1, 23, 39),
+                                   ("3x3_24", 1, 64, 24, 3, 30, 50)], ids=lambda s: s[0])
+def test_conv_residual_epilogue_is_bit_identical(shape):
+    """epilogue 3: relu(residual + relu(conv)) == the separate dkt_add_relu pass (core/extractor.py:60)."""
+    from dkt_stereo_amd import conv, extractor
+    name, B, cin, cout, k, H, W = shape
+    with conv.use_backend("f16x3"):
+        torch.manual_seed(78)
+        layer = torch.nn.Conv2d(cin, cout, k, padding=k // 2).to(DEV)
+        x = G(_synth.normal((B, cin, H, W), 43, name, scale=1.5))
+        res = G(_synth.normal((B, cout, H, W), 44, name))
+        assert conv.fused_eligible(layer)
+        for relu in (True, False):
+            want = extractor.add_relu(res, conv.conv2d(x, layer, relu=relu))
+            assert torch.equal(conv.conv2d_fused(x, layer, relu=relu, residual=res), want)
+        with pytest.raises(ValueError):
+            conv.conv2d_fused(x, layer, residual=res[:, :1])
+
+
+@torch.no_grad()
+def test_conv_in_norm_refusals():
+    from dkt_stereo_amd import _ffi, conv, extractor
+    with conv.use_backend("f16x3"):
+        wide = torch.nn.Conv2d(64, 256, 3, padding=1).to(DEV)
+        x = G(_synth.normal((1, 64, 16, 40), 45, "ref"))
+        params = extractor.instance_norm_params(torch.nn.InstanceNorm2d(64), x)
+        assert not conv.fused_eligible(wide, True)
+        with pytest.raises(_ffi.DktError):
+            conv.conv2d_fused(x, wide, in_norm=params)
+        with pytest.raises(ValueError):
+            conv.conv2d_fused(x, torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV), in_norm=params[:5])
+
+
+@torch.no_grad()
+def test_encoders_fused_equal_unfused(monkeypatch):
+    """BasicEncoder (instance norm, both images) and MultiBasicEncoder (folded batch norm) with the normalise / join
+    passes folded into the convolutions == the round-1 sequence of separate passes, bit for bit."""
+    from dkt_stereo_amd import conv, extractor
+    torch.manual_seed(5)
+    fnet = extractor.BasicEncoder(output_dim=256, norm_fn='instance', downsample=2).to(DEV).eval()
+    cnet = extractor.MultiBasicEncoder(output_dim=[[128] * 3, [128] * 3], norm_fn='batch', downsample=2).to(DEV).eval()
+    for m in cnet.modules():                                   # non-trivial frozen statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    a = G(_synth.normal((1, 3, 96, 160), 46, "l"))
+    b = G(_synth.normal((1, 3, 96, 160), 46, "r"))
+    with conv.use_backend("f16x3"):
+        outs = {}
+        for fuse in (True, False):
+            monkeypatch.setattr(extractor, "FUSE_ENCODER", fuse)
+            f1, f2 = fnet([a, b])
+            scales = cnet(a, num_layers=3)
+            outs[fuse] = [f1, f2] + [t for s in scales for t in s]
+        for x, y in zip(outs[True], outs[False]):
+            assert torch.equal(x, y)
+
+
+@torch.no_grad()
+def test_encoder_graph_equals_eager_and_follows_changes():
+    """The encoder pass is replayed from a captured graph (both encoder streams inside): same bits as the eager pass,
+    for new images, after an in-place weight update in fnet, and after cnet's frozen batch-norm statistics change."""
+    from dkt_stereo_amd.raft_stereo import _ENCODER_STATES
+    model, sd = _raft()
+    model.graph_encoders = True
+    fresh, _ = _raft()
+    fresh.graph_encoders = False
+    for seed in (0, 1, 2):                     # call 1 captures, calls 2-3 replay with other images
+        i1, i2 = _synth.image_pair(seed, 1, 64, 128, 12)
+        got = model(G(i1), G(i2), iters=4, test_mode=True)[1]
+        assert torch.equal(got, fresh(G(i1), G(i2), iters=4, test_mode=True)[1])
+    st = next(iter(_ENCODER_STATES[model].values()))
+    graph = st["graph"]
+    for m in (model, fresh):
+        m.fnet.layer1[0].conv2.weight.mul_(1.1)
+    a = model(G(i1), G(i2), iters=4, test_mode=True)[1]
+    assert torch.equal(a, fresh(G(i1), G(i2), iters=4, test_mode=True)[1]) and not torch.equal(a, got)
+    assert next(iter(_ENCODER_STATES[model].values()))["graph"] is not graph
+    for m in (model, fresh):
+        m.cnet.layer2[0].norm1.running_var.mul_(1.3)
+    b = model(G(i1), G(i2), iters=4, test_mode=True)[1]
+    assert torch.equal(b, fresh(G(i1), G(i2), iters=4, test_mode=True)[1]) and not torch.equal(a, b)
+    # another shape gets its own capture; encode() alone returns the static outputs
+    j1, j2 = _synth.image_pair(5, 1, 96, 160, 10)
+    assert torch.equal(model(G(j1), G(j2), iters=4, test_mode=True)[1], fresh(G(j1), G(j2), iters=4, test_mode=True)[1])
+    f1 = model.encode(G(j1), G(j2))[0]
+    assert torch.equal(f1, fresh.encode(G(j1), G(j2))[0])

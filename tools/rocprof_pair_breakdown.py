@@ -18,6 +18,8 @@ def main():
                     help="also list every dispatch of GRU iteration IT of the pair (start offset, duration, grid)")
     ap.add_argument("--phases", action="store_true", help="split the pair into the GRU loop (corr build .. last "
                     "iteration) and the rest (upsampling + the next pair's encoders)")
+    ap.add_argument("--encoders", action="store_true", help="with --phases: also list every dispatch of the "
+                    "up-sampling + encoder phase (start offset, duration, queue)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -41,6 +43,15 @@ def main():
         end = lk[-1] + (lk[-1] - lk[-2])          # the last iteration is as long as the one before it
         table(win[:end], a.top, "GRU loop (corr build + %d iterations)" % len(lk))
         table(win[end:], a.top, "upsampling + encoders")
+        if a.encoders:
+            t0 = int(win[end]["Start_Timestamp"])
+            print("# dispatches of the up-sampling + encoder phase (start offset us, duration us, end offset us, queue, kernel, grid)")
+            for r in win[end:]:
+                n = re.sub(r"^void ", "", re.sub(r"\(.*", "", r["Kernel_Name"]))[:64]
+                print("%9.1f %9.1f %9.1f  q%-3s %-64s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
+                                                 (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                                 (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"), n,
+                                                 r.get("Grid_Size_X", r.get("Grid_Size", ""))))
     else:
         table(win, a.top, "one steady-state pair")
 
