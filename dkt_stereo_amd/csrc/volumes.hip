@@ -61,6 +61,11 @@ __global__ __launch_bounds__(256) void gwc_volume_kernel(const float *__restrict
 // per SIMD hide the LDS and store latency), and the sum stays the reference's: s = s + r_j * t_j over the group's channels in
 // ascending order, products rounded before they are added, mean by the same division.  Bit-identical.
 typedef float gwc_f2 __attribute__((ext_vector_type(2)));
+typedef float gwc_f4 __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) gwc_f4 *gwc_lds_f4p;
+#ifndef GWC_ABL
+#define GWC_ABL 0      // timing-only ablations: 1 = no global loads, 2 = no compute (LDS reads + math), 4 = no stores
+#endif
 template <bool VEC>
 __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__restrict__ ref,
                                                               const float *__restrict__ tgt,
@@ -75,6 +80,46 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
     const int rpitch = (W + 7) & ~3;                                 // reference rows: 16-byte aligned quads
     const int pitch = lpad + rpitch;
     float *rlds = gwc_lds + cpg * pitch;
+    if (VEC) {
+        // rows are 16-byte aligned (W % 4 == 0): wave k stages channels k, k+4, ...; its lanes walk the row's quads.
+        // All of a thread's loads are issued before the first LDS write (one round trip per block).
+        const int nq4 = W >> 2, wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        for (int j0 = wv; j0 < cpg; j0 += 16) {
+            float4 v[4][2], u[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // clamped (always valid) addresses: the loads stay unconditional, so all 16 are in flight at once
+                    const int j = min(j0 + 4 * k, cpg - 1), wq = min(ln + 64 * q, nq4 - 1);
+                    const size_t o = chan0 + (size_t)j * HW + 4 * wq;
+                    if (GWC_ABL & 1) {
+                        v[k][q] = u[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        v[k][q] = *(const float4 *)(tgt + o);
+                        u[k][q] = *(const float4 *)(ref + o);
+                    }
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = j0 + 4 * k, wq = ln + 64 * q;
+                    if (j < cpg && wq < nq4) {
+                        *(float4 *)(gwc_lds + j * pitch + lpad + 4 * wq) = v[k][q];
+                        *(float4 *)(rlds + j * rpitch + 4 * wq) = u[k][q];
+                    }
+                }
+            for (int wq = ln + 128; wq < nq4; wq += 64)            // rows wider than 512 pixels: the rest, plainly
+                for (int k = 0; k < 4; ++k) {
+                    const int j = j0 + 4 * k;
+                    if (j < cpg) {
+                        *(float4 *)(gwc_lds + j * pitch + lpad + 4 * wq) = *(const float4 *)(tgt + chan0 + (size_t)j * HW + 4 * wq);
+                        *(float4 *)(rlds + j * rpitch + 4 * wq) = *(const float4 *)(ref + chan0 + (size_t)j * HW + 4 * wq);
+                    }
+                }
+        }
+    } else {
     const int n_el = cpg * W;
     for (int i0 = threadIdx.x; i0 < n_el; i0 += 256 * 4) {          // both row sets -> LDS, 8 loads in flight
         float v[4], u[4];
@@ -82,8 +127,8 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
         for (int k = 0; k < 4; ++k) {
             const int i = i0 + 256 * k;
             const int j = i / W, w = i - j * W;
-            v[k] = i < n_el ? tgt[chan0 + (size_t)j * HW + w] : 0.0f;
-            u[k] = i < n_el ? ref[chan0 + (size_t)j * HW + w] : 0.0f;
+            v[k] = (i < n_el && !(GWC_ABL & 1)) ? tgt[chan0 + (size_t)j * HW + w] : 0.0f;
+            u[k] = (i < n_el && !(GWC_ABL & 1)) ? ref[chan0 + (size_t)j * HW + w] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -95,10 +140,13 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
             }
         }
     }
+    }
     __syncthreads();
     const float fcpg = (float)cpg;
     const bool pow2 = (cpg & (cpg - 1)) == 0;                        // such a mean divides exactly by multiplication
     const float rcp = 1.0f / fcpg;
+    // (Splitting the disparity quads over grid.y -- more, smaller blocks -- measured slower: 56 / 69 / 116 us with
+    // 4 / 6 / 12 blocks per row against 50 us: the row loads are repeated per block.)
     const int nq = (W + 3) / 4, ndq = (D + 3) / 4;
     float *vrow = vol + (size_t)b * vol_bstride + (size_t)g * D * HW + (size_t)h * W;
     for (int item = threadIdx.x; item < nq * ndq; item += 256) {
@@ -111,9 +159,13 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) s[dd][0] = s[dd][1] = gwc_f2{0.0f, 0.0f};
 #pragma unroll 4
-        for (int j = 0; j < cpg; ++j) {
-            const float4 rq = *(const float4 *)(rp + j * rpitch);    // (entries past W feed unstored outputs only)
-            const float4 ta = *(const float4 *)(tp + j * pitch), tb = *(const float4 *)(tp + j * pitch + 4);
+        for (int j = 0; j < ((GWC_ABL & 2) ? 1 : cpg); ++j) {
+            // every term of these addresses is a multiple of 4 floats: tell the compiler (ds_read_b128, not 2 x ds_read2_b32)
+            const float4 rq = *(const float4 *)__builtin_assume_aligned(rp + j * rpitch, 16);    // (entries past W feed unstored outputs only)
+            // (volatile: the compiler would otherwise narrow the two quads to the 7 floats used and read them as 4 pieces)
+            // (LDS address space kept explicit: a volatile access through a generic pointer becomes a flat load)
+            gwc_lds_f4p tq = (gwc_lds_f4p)(tp + j * pitch);
+            const gwc_f4 ta = tq[0], tb = tq[1];
             const float t8[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
             const gwc_f2 r01{rq.x, rq.y}, r23{rq.z, rq.w};
             // packed fp32: v_pk_mul_f32 then v_pk_add_f32 (never fused: the reference rounds the product first)
@@ -132,6 +184,7 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = (w + i >= d) ? (pow2 ? __fmul_rn(sv[i], rcp) : __fdiv_rn(sv[i], fcpg)) : 0.0f;
             float *dst = vrow + (size_t)d * HW + w;
+            if ((GWC_ABL & 4) && o[0] != 12345.0f) continue;
             if (VEC && w + 3 < W) {
                 *(float4 *)dst = make_float4(o[0], o[1], o[2], o[3]);
             } else {
@@ -245,6 +298,7 @@ extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
         const size_t lds_q = (size_t)cpg * (lpad + 2 * rp) * sizeof(float);
         dim3 grid((unsigned)blocks), blk(256);
         hipStream_t st = (hipStream_t)stream;
+
         if (legacy || lds_q > 64 * 1024)
             hipLaunchKernelGGL(gwc_volume_kernel, grid, blk, lds, st, ref, tgt, vol, C, H, W, D, G, vol_bstride);
         else if (vec)
