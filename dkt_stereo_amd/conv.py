@@ -178,6 +178,7 @@ def clear_weight_cache(module):
             m.__dict__.pop("_dkt_folded", None)
             m.__dict__.pop("_dkt_stem7", None)
             m.__dict__.pop("_dkt_wt", None)
+            m.__dict__.pop("_dkt_view", None)
             if hasattr(m, "_zr_cache"):
                 m._zr_cache = None
 

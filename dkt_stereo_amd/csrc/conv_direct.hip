@@ -275,8 +275,15 @@ __global__ __launch_bounds__(64 * FEW_NW) void conv3x3_few_kernel(DirectArgs a) 
 template <int TO>
 static int launch_few(DirectArgs a, int B, hipStream_t st) {
     const int cq = (a.Cin + FEW_NW - 1) / FEW_NW;
-    const size_t lds = ((size_t)FEW_NW * 2 * FEW_CC * FEW_PR * FEW_PCP + (size_t)FEW_NW * cq * TO * 12) * sizeof(float);
-    if (lds > 160 * 1024) return DKT_E_UNSUPPORTED;
+    const size_t need = ((size_t)FEW_NW * 2 * FEW_CC * FEW_PR * FEW_PCP + (size_t)FEW_NW * cq * TO * 12) * sizeof(float);
+    if (need > 160 * 1024) return DKT_E_UNSUPPORTED;
+    // The block always asks for the CU's WHOLE LDS (160 KB), whatever it needs.  Measured on MI355X / ROCm 7.2: when a
+    // block of ANOTHER kernel that holds LDS is resident on the same CU (the TO = 1 form needs 123 KB, which leaves room
+    // for a 33 KB block of the 1/16-resolution GRU convolution running on the second stream), the global_load_lds
+    // copies of this kernel do not arrive in its buffers -- 1000 of 1200 launches wrong in tools/stress_lds_dma.py, the
+    // co-resident kernel's results intact -- while the same launches are exact whenever the block has the CU's LDS to
+    // itself (allocation base 0).  Taking all of it makes that the only case.
+    const size_t lds = 160 * 1024;
     auto kern = conv3x3_few_kernel<TO>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

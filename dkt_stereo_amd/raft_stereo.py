@@ -338,9 +338,12 @@ class RAFTStereo(nn.Module):
         nets[0], nets[2] = gru_pair(ub.gru08, (nets[0], *inp[0], [mf, hold["up16"]], nets[0]),
                                     ub.gru32, (nets[2], *inp[2], [hold["pool16"]], nets[2]))
 
+    #: the rotated loop computes only the x output of flow_head.conv2 (DKT_HEAD_X_ONLY=0: both, y dropped afterwards)
+    head_x_only = os.environ.get("DKT_HEAD_X_ONLY", "1") != "0"
+
     def _stage_head(self, nets, coords1, need_mask):
         ub = self.update_block
-        delta_flow = ub.flow_head(nets[0])
+        delta_flow = ub.flow_head(nets[0], outputs=1 if self.head_x_only else None)   # the y component is discarded (raft_stereo.py:165)
         mask = None
         if need_mask:
             mask = .25 * conv2d(conv2d(nets[0], ub.mask[0], relu=True), ub.mask[2])

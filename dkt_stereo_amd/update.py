@@ -153,8 +153,41 @@ class FlowHead(nn.Module):
         self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
         self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
 
-    def forward(self, x):
-        return conv2d(conv2d(x, self.conv1, relu=True), self.conv2)
+    def forward(self, x, outputs=None):
+        """outputs=n: only the first n output channels of conv2 (the stereo callers drop the y component,
+        raft_stereo.py:165: ``delta_flow[:,1] = 0.0`` -- not computing it halves the tail layer's work)."""
+        head = self.conv2 if outputs is None or outputs >= self.conv2.out_channels else _leading_outputs(self.conv2, outputs)
+        return conv2d(conv2d(x, self.conv1, relu=True), head)
+
+
+class _LayerView:
+    """The first n output channels of a convolution layer (duck-types the `layer` argument of conv.conv2d)."""
+
+    def __init__(self, layer, n):
+        self._parent = layer
+        self.weight = layer.weight[:n]
+        self.bias = None if layer.bias is None else layer.bias[:n]
+        self.padding, self.stride, self.dilation, self.groups = layer.padding, layer.stride, layer.dilation, layer.groups
+        self.padding_mode = layer.padding_mode
+        self._key = (layer.weight.data_ptr(), layer.weight._version,
+                     None if layer.bias is None else (layer.bias.data_ptr(), layer.bias._version), n)
+
+    @property
+    def dkt_in_exp(self):                      # the activation exponent (conv.calibrate) lives on the real layer
+        return getattr(self._parent, "dkt_in_exp", 0)
+
+    @dkt_in_exp.setter
+    def dkt_in_exp(self, e):
+        self._parent.dkt_in_exp = e
+
+
+def _leading_outputs(layer, n):
+    key = (layer.weight.data_ptr(), layer.weight._version,
+           None if layer.bias is None else (layer.bias.data_ptr(), layer.bias._version), n)
+    view = layer.__dict__.get("_dkt_view")
+    if view is None or view._key != key:
+        view = layer.__dict__["_dkt_view"] = _LayerView(layer, n)
+    return view
 
 
 class DispHead(FlowHead):

@@ -521,7 +521,8 @@ def test_evaluation_chain_matches_reference(golden, tmp_path):
 # ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [("flow_head", 1, 256, 2, 184, 312, False), ("disp_head", 2, 256, 1, 33, 70, False),
                                    ("odd", 1, 37, 3, 9, 130, True), ("c4", 3, 40, 4, 8, 8, True), ("one_px", 1, 5, 2, 1, 1, False),
-                                   ("narrow", 1, 256, 2, 5, 3, False)], ids=lambda s: s[0])
+                                   ("narrow", 1, 256, 2, 5, 3, False), ("vec_ragged", 2, 50, 2, 7, 20, True),
+                                   ("x_only", 1, 256, 1, 46, 80, False)], ids=lambda s: s[0])
 @torch.no_grad()
 def test_few_output_conv3x3(shape):
     """conv2d routes 3x3 layers with <= 4 outputs to dkt_conv2d_direct's DMA-staged kernel: exact fp32 FMAs,
@@ -666,3 +667,65 @@ def test_encoder_graph_equals_eager_and_follows_changes():
     assert torch.equal(model(G(j1), G(j2), iters=4, test_mode=True)[1], fresh(G(j1), G(j2), iters=4, test_mode=True)[1])
     f1 = model.encode(G(j1), G(j2))[0]
     assert torch.equal(f1, fresh.encode(G(j1), G(j2))[0])
+
+
+@torch.no_grad()
+def test_flow_head_leading_outputs():
+    """FlowHead(x, outputs=1) -- what the stereo loop asks for, the y component being discarded
+    (raft_stereo.py:165) -- is the x plane of the full head, bit for bit, and follows weight updates."""
+    from dkt_stereo_amd import conv, update
+    with conv.use_backend("f16x3"):
+        torch.manual_seed(3)
+        head = update.FlowHead(128, 256, 2).to(DEV)
+        x = G(_synth.normal((2, 128, 37, 64), 61, "fh"))
+        full = head(x)
+        assert torch.equal(head(x, outputs=1), full[:, :1])
+        assert torch.equal(head(x, outputs=2), full)
+        head.conv2.weight.mul_(1.5)
+        assert torch.equal(head(x, outputs=1), head(x)[:, :1]) and not torch.equal(head(x)[:, :1], full[:, :1])
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("cout", [1, 2])
+def test_few_output_kernel_beside_an_lds_holding_kernel(cout):
+    """The DMA-staged head kernel must be exact when blocks of another kernel with LDS run on the same CUs (second
+    stream of the rotated loop): regression for wrong results of the 1-output form, whose 123 KB left room for a 33 KB
+    block of the 1/16 GRU convolution (tools/stress_lds_dma.py)."""
+    from dkt_stereo_amd import conv
+    with conv.use_backend("f16x3"):
+        torch.manual_seed(0)
+        layer = torch.nn.Conv2d(256, cout, 3, padding=1).to(DEV)
+        small = torch.nn.Conv2d(384, 256, 3, padding=1).to(DEV)
+        xs = torch.randn(1, 384, 32, 64, device=DEV)
+        x = torch.randn(1, 256, 64, 128, device=DEV)
+        ref = conv.conv2d(x, layer).clone()
+        ref_s = conv.conv2d(xs, small, relu=True).clone()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        ys, yf = [], []
+        with torch.cuda.graph(g):
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    ys.append(conv.conv2d(xs, small, relu=True))
+            for _ in range(12):
+                yf.append(conv.conv2d(x, layer))
+            main.wait_stream(side)
+        for _ in range(25):
+            g.replay()
+            torch.cuda.synchronize()
+            assert all(torch.equal(y, ref) for y in yf)
+            assert all(torch.equal(y, ref_s) for y in ys)
+
+
+@torch.no_grad()
+def test_raft_forward_is_deterministic_at_small_scales():
+    """256x512 (64x128 at 1/4, 16x32 at 1/16): the scale at which small kernels of both streams share CUs.
+    Twelve forwards, one result."""
+    model, _ = _raft()
+    i1, i2 = _synth.image_pair(1, 1, 256, 512, 20)
+    ref = model(G(i1), G(i2), iters=8, test_mode=True)[1].clone()
+    for _ in range(11):
+        assert torch.equal(model(G(i1), G(i2), iters=8, test_mode=True)[1], ref)

@@ -82,8 +82,10 @@ def main():
     T("flow_head conv1 128->256", lambda: conv2d(net[0], ub.flow_head.conv1, relu=True))
     y = conv2d(net[0], ub.flow_head.conv1, relu=True)
     T("flow_head conv2 256->2", lambda: conv2d(y, ub.flow_head.conv2))
+    from dkt_stereo_amd.update import _leading_outputs
+    T("flow_head conv2, x output only", lambda: conv2d(y, _leading_outputs(ub.flow_head.conv2, 1)))
     tot = sum(us for n, us in rows if n not in ("lookup (skew)", "convc1 1x1 36->64", "convc2 64->64", "convf1 7x7 2->64",
-                                                 "convf2 64->64", "enc.conv 128->126", "lookup+convc1 fused", "lookup on the fly (alt)", "gru08 + gru32 paired"))
+                                                 "convf2 64->64", "enc.conv 128->126", "lookup+convc1 fused", "lookup on the fly (alt)", "gru08 + gru32 paired", "flow_head conv2, x output only"))
     print("sum of stand-alone stage times      %8.1f us" % tot)
     # the whole pipelined iteration as the harness runs it
     i1, i2 = _synth.image_pair(3, B, 736, 1248, 40)
