@@ -256,6 +256,17 @@ def test_streaming_helpers_vs_torch():
         assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-6
         odd = torch.empty(B, C, 2 * H + 1, 2 * W - 1, device=DEV)
         assert float((interp(x, odd) - F.interpolate(x, odd.shape[2:], mode="bilinear", align_corners=True)).abs().max()) <= 2e-6
+    for (B, C, H, W) in ((2, 3, 10, 16), (1, 2, 9, 640), (1, 4, 1, 8), (3, 1, 6, 24)):      # wide / tiny / batched planes
+        x = G(_synth.normal((B, C, H, W), 96, "p%d" % H))
+        want = F.avg_pool2d(x, 3, stride=2, padding=1)
+        got = pool2x(x)
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-6
+    # the LDS-staged up-sampling form (16-byte aligned rows): the loop's 1/8 -> 1/4 resize, ragged row blocks, non-2x scales
+    for (B, C, H, W, Ho, Wo) in ((1, 16, 92, 156, 184, 312), (2, 3, 20, 24, 37, 44), (1, 2, 8, 8, 8, 8), (1, 5, 33, 640, 70, 1000)):
+        x = G(_synth.normal((B, C, H, W), 95, "u%d" % H))
+        want = F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=True)
+        got = interp(x, torch.empty(B, C, Ho, Wo, device=DEV))
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-6
     from dkt_stereo_amd.extractor import norm_add_relu
     inorm = torch.nn.InstanceNorm2d(8)
     for (B, C, H, W) in ((2, 8, 33, 47), (1, 8, 64, 128), (1, 8, 3, 5)):
