@@ -330,7 +330,12 @@ class RAFTStereo(nn.Module):
         corr = self._lookup(corr_fn, coords1)
         if hasattr(corr, "materialize"):
             corr = _Precomputed(enc._cor1(corr))
-        return enc(coords1 - coords0, corr)
+        # the flow is computed straight into the tail channels of the motion-feature buffer (no copy for the torch.cat
+        # of core/update.py:85)
+        b, _, h, w = coords1.shape
+        _, flow = enc.new_feature_buffer(b, h, w, coords1.device)
+        torch.sub(coords1, coords0, out=flow)
+        return enc(flow, corr)
 
     def _stage_fine(self, nets, inp, mf, hold):
         """gru08 of this iteration and gru32 of the next one in shared launches (update.gru_pair)."""

@@ -360,10 +360,29 @@ class BasicMotionEncoder(nn.Module):
         # channels of the 128-channel motion-feature buffer (no torch.cat of the big part)
         B, _, H, W = flow.shape
         nout = self.conv.weight.shape[0]
-        feat = torch.empty((B, nout + flow.shape[1], H, W), device=flow.device, dtype=torch.float32)
+        feat = self.feature_buffer_of(flow)
+        if feat is None:
+            feat = torch.empty((B, nout + flow.shape[1], H, W), device=flow.device, dtype=torch.float32)
+            feat[:, nout:] = flow
         conv2d([cor, flo], self.conv, relu=True, out=feat[:, :nout])
-        feat[:, nout:] = flow
         return feat
+
+    def new_feature_buffer(self, B, H, W, device):
+        """(feat, flow_view): the 128-channel motion-feature buffer and its trailing flow / disparity channels.  A
+        caller that computes the flow straight into ``flow_view`` (torch.sub(..., out=flow_view)) and passes that view
+        as ``flow`` saves the copy of core/update.py:85's torch.cat."""
+        nout = self.conv.weight.shape[0]
+        feat = torch.empty((B, nout + self._aux_ch, H, W), device=device, dtype=torch.float32)
+        view = feat[:, nout:]
+        view._dkt_feat = feat
+        return feat, view
+
+    def feature_buffer_of(self, flow):
+        feat = getattr(flow, "_dkt_feat", None)
+        if (feat is not None and feat.shape[1] == self.conv.weight.shape[0] + flow.shape[1]
+                and flow.data_ptr() == feat[:, self.conv.weight.shape[0]:].data_ptr() and feat.shape[2:] == flow.shape[2:]):
+            return feat
+        return None
 
 
 class BasicMotionEncoderIGEV(BasicMotionEncoder):
