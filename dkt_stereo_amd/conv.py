@@ -257,6 +257,28 @@ def _conv2d_direct(x, layer, relu, out):
     return out
 
 
+def conv2d_accumulate(x, layer, out):
+    """out += conv(x) + bias for a few-output 3x3 layer (``few_eligible``): the head layer of the refinement loop adds its
+    result to the running coordinates / disparity in its epilogue (one elementwise launch less per iteration).
+    `out`: (B, Cout, H, W) view, dense per batch element."""
+    _ffi.require_gpu(x, out)
+    _ffi.require_no_grad(x)
+    if not _dense(x):
+        x = x.contiguous()
+    B, cin, H, W = x.shape
+    cout, _, kh, kw = layer.weight.shape
+    if not _dense(out) or out.dtype != torch.float32 or tuple(out.shape) != (B, cout, H, W):
+        raise ValueError("conv2d_accumulate(out=...) must be a dense-per-batch fp32 tensor of the result shape")
+    w = layer.weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    b = layer.bias
+    rc = _ffi.lib().dkt_conv2d_direct_accumulate(x.data_ptr(), x.stride(0), w.data_ptr(), None if b is None else b.data_ptr(),
+                                                 out.data_ptr(), out.stride(0), B, cin, cout, H, W, kh, kw,
+                                                 _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_conv2d_direct_accumulate")
+    return out
+
+
 def _conv2d_stem7(x, layer, relu, out):
     """7x7 stem (Cin <= 4) on the matrix cores (dkt_conv2d_stem7); packed weights cached on the layer."""
     _ffi.require_gpu(x)

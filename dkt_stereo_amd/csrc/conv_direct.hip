@@ -18,6 +18,7 @@ struct DirectArgs {
     long y_bs;
     int Cin, Cout, H, W, tiles_w;
     int relu;
+    int accumulate;      // few-output 3x3 form only: y += result (the loop's coords1 += delta in the head's epilogue)
 };
 
 // Thread = 4 horizontally adjacent pixels x TO output channels (register blocking: the 4 + 2*HALO
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64 * FEW_NW) void conv3x3_few_kernel(DirectArgs a) 
             for (int ww = 1; ww < FEW_NW; ++ww) v = __fadd_rn(v, part[((ww * TO + o) * 4 + p) * 64 + lane]);
             v = __fadd_rn(v, bias);
             if (a.relu) v = dkt_relu(v);
-            yr[p] = v;
+            yr[p] = a.accumulate ? __fadd_rn(yr[p], v) : v;
         }
     }
 }
@@ -301,9 +302,26 @@ static int launch_direct(const DirectArgs &a, int B, hipStream_t st) {
     return dkt_launch_status();
 }
 
+static int conv2d_direct_impl(const float *x, long x_bstride, const float *w, const float *bias,
+                              float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
+                              int KH, int KW, int relu, int accumulate, int device, void *stream);
+
 extern "C" int dkt_conv2d_direct(const float *x, long x_bstride, const float *w, const float *bias,
                                  float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
                                  int KH, int KW, int relu, int device, void *stream) {
+    return conv2d_direct_impl(x, x_bstride, w, bias, y, y_bstride, B, Cin, Cout, H, W, KH, KW, relu, 0, device, stream);
+}
+
+extern "C" int dkt_conv2d_direct_accumulate(const float *x, long x_bstride, const float *w, const float *bias,
+                                            float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
+                                            int KH, int KW, int device, void *stream) {
+    if (KH != 3 || Cout > 4) return DKT_E_UNSUPPORTED;
+    return conv2d_direct_impl(x, x_bstride, w, bias, y, y_bstride, B, Cin, Cout, H, W, KH, KW, 0, 1, device, stream);
+}
+
+static int conv2d_direct_impl(const float *x, long x_bstride, const float *w, const float *bias,
+                              float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
+                              int KH, int KW, int relu, int accumulate, int device, void *stream) {
     if (!x || !w || !y) return DKT_E_NULL;
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || B > 65535) return DKT_E_SHAPE;
     if (KH != KW || (KH != 3 && KH != 7)) return DKT_E_UNSUPPORTED;
@@ -311,12 +329,13 @@ extern "C" int dkt_conv2d_direct(const float *x, long x_bstride, const float *w,
     a.x = x; a.x_bs = x_bstride; a.w = w; a.bias = bias; a.y = y; a.y_bs = y_bstride;
     a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.tiles_w = (W + 63) / 64;
     a.relu = relu ? 1 : 0;
+    a.accumulate = accumulate ? 1 : 0;
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
     if (KH == 3) {
         if (Cout > 4) return DKT_E_UNSUPPORTED;       // wide layers belong to dkt_conv2d_f16s
         static const bool old = [] { const char *e = getenv("DKT_DIRECT_LEGACY"); return e && atoi(e) != 0; }();
-        if (old) return Cout <= 2 ? launch_direct<3, 2, 8>(a, B, st) : launch_direct<3, 4, 8>(a, B, st);
+        if (old && !accumulate) return Cout <= 2 ? launch_direct<3, 2, 8>(a, B, st) : launch_direct<3, 4, 8>(a, B, st);
         if (Cout <= 1) return launch_few<1>(a, B, st);
         if (Cout <= 2) return launch_few<2>(a, B, st);
         return launch_few<4>(a, B, st);

@@ -348,11 +348,15 @@ class RAFTStereo(nn.Module):
 
     def _stage_head(self, nets, coords1, need_mask):
         ub = self.update_block
-        delta_flow = ub.flow_head(nets[0], outputs=1 if self.head_x_only else None)   # the y component is discarded (raft_stereo.py:165)
+        if self.head_x_only:
+            # stereo: only x moves (raft_stereo.py:165-168) -- the y output is not computed, and the x output is added
+            # to coords1 in the tail layer's epilogue
+            ub.flow_head.add_to(nets[0], coords1[:, :1], outputs=1)
+        else:
+            coords1[:, :1].add_(ub.flow_head(nets[0])[:, :1])
         mask = None
         if need_mask:
             mask = .25 * conv2d(conv2d(nets[0], ub.mask[0], relu=True), ub.mask[2])
-        coords1[:, :1].add_(delta_flow[:, :1])           # stereo: only x moves (raft_stereo.py:165-168)
         return mask
 
     def _rotated_unit(self, st):

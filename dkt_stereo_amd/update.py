@@ -29,8 +29,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ffi
-from .conv import (_CACHE_LOCK, conv2d, conv2d_gate_out, conv2d_gate_out_pair, conv2d_gate_zr, conv2d_gate_zr_pair, conv2d_pair,
-                   get_backend, hip_eligible, pair_eligible)
+from .conv import (_CACHE_LOCK, conv2d, conv2d_accumulate, conv2d_gate_out, conv2d_gate_out_pair, conv2d_gate_zr,
+                   conv2d_gate_zr_pair, conv2d_pair, few_eligible, get_backend, hip_eligible, pair_eligible)
 
 
 class _Harness(threading.local):
@@ -158,6 +158,15 @@ class FlowHead(nn.Module):
         raft_stereo.py:165: ``delta_flow[:,1] = 0.0`` -- not computing it halves the tail layer's work)."""
         head = self.conv2 if outputs is None or outputs >= self.conv2.out_channels else _leading_outputs(self.conv2, outputs)
         return conv2d(conv2d(x, self.conv1, relu=True), head)
+
+    def add_to(self, x, target, outputs=None):
+        """target += head(x) in the tail layer's epilogue when it runs on the few-output kernel (else the plain add).
+        `target`: (B, outputs, H, W) view of the running coordinates / disparity."""
+        head = self.conv2 if outputs is None or outputs >= self.conv2.out_channels else _leading_outputs(self.conv2, outputs)
+        hidden = conv2d(x, self.conv1, relu=True)
+        if few_eligible(head) and target.is_cuda:
+            return conv2d_accumulate(hidden, head, target)
+        return target.add_(conv2d(hidden, head))
 
 
 class _LayerView:

@@ -350,6 +350,11 @@ int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const voi
 int dkt_conv2d_direct(const float *x, long x_bstride, const float *w, const float *bias,
                       float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
                       int KH, int KW, int relu, int device, void *stream);
+/* The 3x3 few-output form with y += conv(x) + bias: the disparity update of the refinement loop
+ * (raft_stereo.py:165-168: coords1 = coords1 + delta_flow; igev_stereo.py:209) in the head layer's epilogue. */
+int dkt_conv2d_direct_accumulate(const float *x, long x_bstride, const float *w, const float *bias,
+                                 float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
+                                 int KH, int KW, int device, void *stream);
 
 /* ---- streaming helpers around the convolutions ---------------------------------------- */
 

@@ -729,3 +729,23 @@ def test_raft_forward_is_deterministic_at_small_scales():
     ref = model(G(i1), G(i2), iters=8, test_mode=True)[1].clone()
     for _ in range(11):
         assert torch.equal(model(G(i1), G(i2), iters=8, test_mode=True)[1], ref)
+
+
+@torch.no_grad()
+def test_head_accumulate_epilogue():
+    """target += head(x) inside the few-output kernel == the separate add, bit for bit (dkt_conv2d_direct_accumulate);
+    the target is a channel slice of a wider tensor, as coords1[:, :1] is."""
+    from dkt_stereo_amd import conv, update
+    with conv.use_backend("f16x3"):
+        torch.manual_seed(9)
+        head = update.FlowHead(128, 256, 2).to(DEV)
+        x = G(_synth.normal((2, 128, 30, 52), 71, "acc"))
+        coords = G(_synth.normal((2, 2, 30, 52), 72, "coords", scale=20.0))
+        want = coords.clone()
+        want[:, :1] += head(x)[:, :1]
+        got = coords.clone()
+        head.add_to(x, got[:, :1], outputs=1)
+        assert torch.equal(got, want)
+        both = coords.clone()
+        head.add_to(x, both)
+        assert torch.equal(both, coords + head(x))
