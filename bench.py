@@ -351,7 +351,7 @@ def main():
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
         # the kernel BASELINE.json's north_star sets the HBM target for
-        "roofline_lookup": {"kernel": ("corr_feat_kernel<4,4,2> (dkt_corr1d_lookup_conv1x1): pyramid lookup fused with "
+        "roofline_lookup": {"kernel": ("corr_feat16_kernel<4,4> (dkt_corr1d_lookup_conv1x1): pyramid lookup fused with "
                                        "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA") if fused_lookup
                             else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
