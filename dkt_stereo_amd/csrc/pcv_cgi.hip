@@ -110,13 +110,26 @@ __global__ __launch_bounds__(256) void group_l2norm_kernel(const float *__restri
         const long p = i - bg * HW;
         const float *src = x + bg * cpg * HW + p;
         float *dst = y + bg * cpg * HW + p;
+        // sixteen channel planes in flight per thread (the plain loop waited for every load before issuing the next:
+        // 46 us for 96 channels at 184x312); the sum keeps its ascending channel order
         float s = 0.0f;
-        for (int j = 0; j < cpg; ++j) {
-            const float v = src[(long)j * HW];
-            s = __fadd_rn(s, __fmul_rn(v, v));
+        for (int j0 = 0; j0 < cpg; j0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = src[(long)min(j0 + j, cpg - 1) * HW];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j0 + j < cpg) s = __fadd_rn(s, __fmul_rn(v[j], v[j]));
         }
         const float d = __fadd_rn(__fsqrt_rn(s), eps);
-        for (int j = 0; j < cpg; ++j) dst[(long)j * HW] = __fdiv_rn(src[(long)j * HW], d);
+        for (int j0 = 0; j0 < cpg; j0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = src[(long)min(j0 + j, cpg - 1) * HW];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j0 + j < cpg) dst[(long)(j0 + j) * HW] = __fdiv_rn(v[j], d);
+        }
     }
 }
 

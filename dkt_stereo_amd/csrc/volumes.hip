@@ -196,6 +196,116 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
     }
 }
 
+// Wide groups (CGI's single-group normalised correlation: 96 channels per group) on the quad form: the group's rows
+// do not fit the LDS at once, so they pass through it in chunks of GWC_CH channels while every thread keeps the
+// 16 partial sums of each of its (up to GWC_NI) work items in registers across the chunks.  Same ascending-channel
+// summation as the reference.  Needs 16-byte aligned rows (W % 4 == 0) and ceil(W/4) * ceil(D/4) <= 256 * GWC_NI.
+#define GWC_CH 16
+#define GWC_NI 4
+__global__ __launch_bounds__(256) void gwc_volume_quad_chunked_kernel(const float *__restrict__ ref,
+                                                                      const float *__restrict__ tgt,
+                                                                      float *__restrict__ vol, int C, int H, int W,
+                                                                      int D, int G, long vol_bstride, int lpad) {
+    const int cpg = C / G;
+    const int h = blockIdx.x % H;
+    const int g = (blockIdx.x / H) % G;
+    const int b = blockIdx.x / (H * G);
+    const size_t HW = (size_t)H * W;
+    const size_t chan0 = ((size_t)b * C + (size_t)g * cpg) * HW + (size_t)h * W;
+    const int rpitch = (W + 7) & ~3;
+    const int pitch = lpad + rpitch;
+    float *rlds = gwc_lds + GWC_CH * pitch;
+    const int nq4 = W >> 2, wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int nq = nq4, ndq = (D + 3) / 4;
+    gwc_f2 s[GWC_NI][4][2];
+#pragma unroll
+    for (int i = 0; i < GWC_NI; ++i)
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) s[i][dd][0] = s[i][dd][1] = gwc_f2{0.0f, 0.0f};
+    int iw[GWC_NI], id0[GWC_NI];
+    bool iok[GWC_NI];
+#pragma unroll
+    for (int i = 0; i < GWC_NI; ++i) {
+        const int item = threadIdx.x + 256 * i;
+        iok[i] = item < nq * ndq;
+        const int dq = (iok[i] ? item : 0) / nq;
+        iw[i] = 4 * ((iok[i] ? item : 0) - dq * nq);
+        id0[i] = 4 * dq;
+    }
+    for (int c0 = 0; c0 < cpg; c0 += GWC_CH) {
+        const int nc = min(GWC_CH, cpg - c0);
+        // stage channels c0 .. c0+nc-1: wave k takes k, k+4, k+8, k+12; all 16 loads of a thread in flight together
+        float4 v[4][2], u[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = min(wv + 4 * k, nc - 1), wq = min(ln + 64 * q, nq4 - 1);
+                const size_t o = chan0 + (size_t)(c0 + j) * HW + 4 * wq;
+                v[k][q] = *(const float4 *)(tgt + o);
+                u[k][q] = *(const float4 *)(ref + o);
+            }
+        __syncthreads();                                            // the previous chunk has been consumed
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = wv + 4 * k, wq = ln + 64 * q;
+                if (j < nc && wq < nq4) {
+                    *(float4 *)(gwc_lds + j * pitch + lpad + 4 * wq) = v[k][q];
+                    *(float4 *)(rlds + j * rpitch + 4 * wq) = u[k][q];
+                }
+            }
+        for (int wq = ln + 128; wq < nq4; wq += 64)                 // rows wider than 512 pixels
+            for (int k = 0; k < 4; ++k) {
+                const int j = wv + 4 * k;
+                if (j < nc) {
+                    *(float4 *)(gwc_lds + j * pitch + lpad + 4 * wq) = *(const float4 *)(tgt + chan0 + (size_t)(c0 + j) * HW + 4 * wq);
+                    *(float4 *)(rlds + j * rpitch + 4 * wq) = *(const float4 *)(ref + chan0 + (size_t)(c0 + j) * HW + 4 * wq);
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < GWC_NI; ++i) {
+            if (!iok[i]) continue;
+            const float *tp = gwc_lds + lpad + iw[i] - id0[i] - 4;
+            const float *rp = rlds + iw[i];
+#pragma unroll 4
+            for (int j = 0; j < nc; ++j) {
+                const float4 rq = *(const float4 *)__builtin_assume_aligned(rp + j * rpitch, 16);
+                gwc_lds_f4p tq = (gwc_lds_f4p)(tp + j * pitch);
+                const gwc_f4 ta = tq[0], tb = tq[1];
+                const float t8[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+                const gwc_f2 r01{rq.x, rq.y}, r23{rq.z, rq.w};
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    s[i][dd][0] = s[i][dd][0] + r01 * gwc_f2{t8[4 - dd], t8[5 - dd]};
+                    s[i][dd][1] = s[i][dd][1] + r23 * gwc_f2{t8[6 - dd], t8[7 - dd]};
+                }
+            }
+        }
+    }
+    const float fcpg = (float)cpg;
+    const bool pow2 = (cpg & (cpg - 1)) == 0;
+    const float rcp = 1.0f / fcpg;
+    float *vrow = vol + (size_t)b * vol_bstride + (size_t)g * D * HW + (size_t)h * W;
+#pragma unroll
+    for (int i = 0; i < GWC_NI; ++i) {
+        if (!iok[i]) continue;
+        const int w = iw[i];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = id0[i] + dd;
+            if (d >= D) break;
+            const float sv[4] = {s[i][dd][0].x, s[i][dd][0].y, s[i][dd][1].x, s[i][dd][1].y};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (w + k >= d) ? (pow2 ? __fmul_rn(sv[k], rcp) : __fdiv_rn(sv[k], fcpg)) : 0.0f;
+            *(float4 *)(vrow + (size_t)d * HW + w) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // Groups wider than GWC_MAX_CPG channels (CGI's single-group normalised correlation: cpg = C):
 // same block mapping and the same sequential sum order, the reference values pass through
 // registers in chunks of 16 channels and the partial sums of a pixel stay in registers.
@@ -284,6 +394,17 @@ extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
         hipError_t e = hipFuncSetAttribute(big ? (const void *)gwc_volume_big_kernel : (const void *)gwc_volume_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+    }
+    const bool vec16 = W % 4 == 0 && vol_bstride % 4 == 0 && ((((uintptr_t)vol) | ((uintptr_t)ref) | ((uintptr_t)tgt)) & 15) == 0;
+    static const bool big_legacy = [] { const char *e = getenv("DKT_GWC_LEGACY"); return e && atoi(e) != 0; }();
+    if (big && vec16 && !big_legacy && (long)((W + 3) / 4) * ((D + 3) / 4) <= 256L * GWC_NI) {
+        const int lpad_c = ((D + 3) & ~3) + 4;
+        const size_t lds_c = (size_t)GWC_CH * (lpad_c + 2 * ((W + 7) & ~3)) * sizeof(float);
+        if (lds_c <= 64 * 1024) {
+            hipLaunchKernelGGL(gwc_volume_quad_chunked_kernel, dim3((unsigned)blocks), dim3(256), lds_c, (hipStream_t)stream,
+                               ref, tgt, vol, C, H, W, D, G, vol_bstride, lpad_c);
+            return dkt_launch_status();
+        }
     }
     if (big)
         hipLaunchKernelGGL(gwc_volume_big_kernel,
