@@ -65,13 +65,27 @@ __global__ __launch_bounds__(256) void pcv_lookup_kernel(PcvArgs a) {
     const float hwm1 = __fdiv_rn(wm1, 2.0f);
     float *o = a.out + (((long)b * a.L + lv) * a.G * a.S + (long)g * a.S) * a.HW + p;
     const int half = a.S / 2;
-    for (int s = 0; s < a.S; ++s) {
-        const float x = __fadd_rn(__fmul_rn((float)(s - half), sg), c);
-        const DktTap tp = dkt_tap(__fdiv_rn(x, div), wm1, hwm1);
-        float v0 = 0.0f, v1 = 0.0f;
-        if (tp.fl >= 0.0f && tp.fl <= wm1) v0 = row[(int)tp.fl];
-        if (tp.fl + 1.0f >= 0.0f && tp.fl + 1.0f <= wm1) v1 = row[(int)tp.fl + 1];
-        o[(long)s * a.HW] = dkt_blend(v0, v1, tp);
+    // batches of 9 samples: the 18 taps are loaded unconditionally (clamped index, zero selected afterwards) so that they
+    // are in flight together -- the guarded form was one branch and one round trip per tap
+    for (int s0 = 0; s0 < a.S; s0 += 9) {
+        DktTap tp[9];
+        float v0[9], v1[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int s = min(s0 + k, a.S - 1);
+            const float x = __fadd_rn(__fmul_rn((float)(s - half), sg), c);
+            tp[k] = dkt_tap(__fdiv_rn(x, div), wm1, hwm1);
+            const float f0 = fminf(fmaxf(tp[k].fl, 0.0f), wm1), f1 = fminf(fmaxf(tp[k].fl + 1.0f, 0.0f), wm1);
+            v0[k] = row[(int)f0];
+            v1[k] = row[(int)f1];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (s0 + k >= a.S) break;
+            const float a0 = (tp[k].fl >= 0.0f && tp[k].fl <= wm1) ? v0[k] : 0.0f;
+            const float a1 = (tp[k].fl + 1.0f >= 0.0f && tp[k].fl + 1.0f <= wm1) ? v1[k] : 0.0f;
+            o[(long)(s0 + k) * a.HW] = dkt_blend(a0, a1, tp[k]);
+        }
     }
 }
 
