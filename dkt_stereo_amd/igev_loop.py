@@ -104,10 +104,8 @@ def _fine(ub, nets, inp, mf, hold):
 
 
 def _head(ub, st, need_mask):
-    delta = ub.disp_head(st.net[0])
-    mask = conv2d(st.net[0], ub.mask_feat_4[0], relu=True) if need_mask else None
-    st.disp.add_(delta)
-    return mask
+    ub.disp_head.add_to(st.net[0], st.disp)          # disp += head(net): the add rides in the tail layer's epilogue
+    return conv2d(st.net[0], ub.mask_feat_4[0], relu=True) if need_mask else None
 
 
 def _rotated_unit(ub, st):
