@@ -67,6 +67,7 @@ SIGNATURES = {
     "dkt_instance_norm_stats": [_vp, _vp, _i, _l, _i, _vp],
     "dkt_instance_norm_add_relu": [_vp, _vp, _vp, _vp, _i, _l, _f, _i, _vp],
     "dkt_instance_norm_finalize": [_vp, _i, _l, _f, _vp, _i, _vp],
+    "dkt_instance_norm_add_relu_lazy": [_vp, _vp, _i, _vp, _vp, _vp, _i, _l, _f, _i, _vp],
     "dkt_conv2d_stem7_packed_elems": [_i],
     "dkt_conv2d_stem7_pack": [_vp, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_stem7": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -158,7 +158,8 @@ extern "C" int dkt_instance_norm_finalize(const void *workspace, int planes, lon
 // Replaces the normalise(+ReLU) pass over c and the separate add+ReLU pass.
 __global__ __launch_bounds__(256) void instnorm_add_relu_kernel(const float *__restrict__ a, const float *__restrict__ c,
                                                                 float *__restrict__ y, const double *__restrict__ part,
-                                                                long HW, int S, float eps, int blocks_per_plane) {
+                                                                long HW, int S, float eps, int blocks_per_plane,
+                                                                const float *__restrict__ a_norm, int a_relu) {
     const int plane = blockIdx.y;
     double sum = 0.0, sq = 0.0;
     for (int s = 0; s < S; ++s) {
@@ -170,6 +171,14 @@ __global__ __launch_bounds__(256) void instnorm_add_relu_kernel(const float *__r
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d;
     const float invstd = 1.0f / sqrtf((float)var_d + eps);
+    // the residual operand may itself be a not-yet-normalised tensor: a' = [relu]((a - mean_a) * invstd_a)
+    const bool an = a_norm != nullptr;
+    const float am = an ? a_norm[2 * plane] : 0.0f, ai = an ? a_norm[2 * plane + 1] : 1.0f;
+    auto res = [&](float u) {
+        if (!an) return u;
+        const float t = (u - am) * ai;
+        return a_relu ? dkt_relu(t) : t;
+    };
     const float *pa = a + (long)plane * HW, *pc = c + (long)plane * HW;
     float *q = y + (long)plane * HW;
     const long stride = (long)blocks_per_plane * 1024;
@@ -177,27 +186,39 @@ __global__ __launch_bounds__(256) void instnorm_add_relu_kernel(const float *__r
         for (long i = blockIdx.x * 1024L + 4L * threadIdx.x; i + 3 < HW; i += stride) {
             const float4 u = *(const float4 *)(pa + i);
             float4 v = *(const float4 *)(pc + i);
-            v.x = dkt_relu(u.x + dkt_relu((v.x - mean) * invstd));
-            v.y = dkt_relu(u.y + dkt_relu((v.y - mean) * invstd));
-            v.z = dkt_relu(u.z + dkt_relu((v.z - mean) * invstd));
-            v.w = dkt_relu(u.w + dkt_relu((v.w - mean) * invstd));
+            v.x = dkt_relu(res(u.x) + dkt_relu((v.x - mean) * invstd));
+            v.y = dkt_relu(res(u.y) + dkt_relu((v.y - mean) * invstd));
+            v.z = dkt_relu(res(u.z) + dkt_relu((v.z - mean) * invstd));
+            v.w = dkt_relu(res(u.w) + dkt_relu((v.w - mean) * invstd));
             *(float4 *)(q + i) = v;
         }
     } else {
         for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)blocks_per_plane * 256)
-            q[i] = dkt_relu(pa[i] + dkt_relu((pc[i] - mean) * invstd));
+            q[i] = dkt_relu(res(pa[i]) + dkt_relu((pc[i] - mean) * invstd));
     }
 }
 
-extern "C" int dkt_instance_norm_add_relu(const float *a, const float *c, float *y, const void *workspace,
-                                          int planes, long HW, float eps, int device, void *stream) {
+static int instnorm_add_relu_impl(const float *a, const float *a_norm, int a_relu, const float *c, float *y,
+                                  const void *workspace, int planes, long HW, float eps, int device, void *stream) {
     if (!a || !c || !y || !workspace) return DKT_E_NULL;
     if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;
     DKT_ENTER(device);
     const int S = instnorm_split(planes, HW);
     hipLaunchKernelGGL(instnorm_add_relu_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, (hipStream_t)stream,
-                       a, c, y, (const double *)workspace, HW, S, eps, S);
+                       a, c, y, (const double *)workspace, HW, S, eps, S, a_norm, a_relu ? 1 : 0);
     return dkt_launch_status();
+}
+
+extern "C" int dkt_instance_norm_add_relu(const float *a, const float *c, float *y, const void *workspace,
+                                          int planes, long HW, float eps, int device, void *stream) {
+    return instnorm_add_relu_impl(a, nullptr, 0, c, y, workspace, planes, HW, eps, device, stream);
+}
+
+extern "C" int dkt_instance_norm_add_relu_lazy(const float *a, const float *a_mean_invstd, int a_relu, const float *c,
+                                               float *y, const void *workspace, int planes, long HW, float eps,
+                                               int device, void *stream) {
+    if (!a_mean_invstd) return DKT_E_NULL;
+    return instnorm_add_relu_impl(a, a_mean_invstd, a_relu, c, y, workspace, planes, HW, eps, device, stream);
 }
 
 __global__ __launch_bounds__(256) void add_relu_kernel(const float *__restrict__ a, const float *__restrict__ b,

@@ -126,6 +126,9 @@ def norm_add_relu(norm, x, c):
     (fnet) the normalisation of c is folded into the join (dkt_instance_norm_stats +
     dkt_instance_norm_add_relu: one pass over c for the statistics, one fused pass), otherwise
     norm_act + add_relu."""
+    lazy = x if isinstance(x, LazyNorm) else None
+    if lazy is not None:
+        x = lazy.raw
     if _plain_instance_norm(norm) and _hip_ok(x) and _hip_ok(c) and x.shape == c.shape:
         x = x.contiguous()
         c = c.contiguous()
@@ -135,11 +138,31 @@ def norm_add_relu(norm, x, c):
         y = torch.empty_like(c)
         rc = L.dkt_instance_norm_stats(c.data_ptr(), ws.data_ptr(), n * ch, h * w, _ffi.device_of(c), _ffi.stream_of(c))
         _ffi.check(rc, "dkt_instance_norm_stats")
-        rc = L.dkt_instance_norm_add_relu(x.data_ptr(), c.data_ptr(), y.data_ptr(), ws.data_ptr(), n * ch, h * w,
-                                          float(norm.eps), _ffi.device_of(c), _ffi.stream_of(c))
+        if lazy is not None:
+            rc = L.dkt_instance_norm_add_relu_lazy(x.data_ptr(), lazy.params.data_ptr(), int(lazy.relu), c.data_ptr(),
+                                                   y.data_ptr(), ws.data_ptr(), n * ch, h * w, float(norm.eps),
+                                                   _ffi.device_of(c), _ffi.stream_of(c))
+        else:
+            rc = L.dkt_instance_norm_add_relu(x.data_ptr(), c.data_ptr(), y.data_ptr(), ws.data_ptr(), n * ch, h * w,
+                                              float(norm.eps), _ffi.device_of(c), _ffi.stream_of(c))
         _ffi.check(rc, "dkt_instance_norm_add_relu")
         return y
+    if lazy is not None:
+        x = lazy.materialize()
     return add_relu(x, norm_act(norm, c, True))
+
+
+class LazyNorm:
+    """[relu](instance_norm(raw)) that has not been evaluated: the raw convolution output and its per-plane
+    (mean, 1/std).  Consumers fold the normalisation into their own pass (conv2d_fused(in_norm=...) reads it in its
+    staging, dkt_instance_norm_add_relu_lazy applies it to the residual operand); ``materialize`` runs the plain pass."""
+
+    def __init__(self, norm, raw, relu):
+        self.norm, self.raw, self.relu = norm, raw, relu
+        self.params = instance_norm_params(norm, raw)
+
+    def materialize(self):
+        return norm_act(self.norm, self.raw, self.relu)
 
 
 def add_relu(a, b):
@@ -191,15 +214,25 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(_Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        fuse = FUSE_ENCODER and _hip_ok(x)
+        lazy = x if isinstance(x, LazyNorm) else None
+        fuse = FUSE_ENCODER and _hip_ok(lazy.raw if lazy is not None else x)
         if fuse and _plain_instance_norm(self.norm1) and _plain_instance_norm(self.norm2) and fused_eligible(self.conv2, True):
             # fnet: relu(norm1(.)) between the two layers lives in conv2's staging (no normalise pass, the
             # intermediate is read once for its statistics and once by conv2)
-            c1 = self.conv1(x)
+            if lazy is not None and lazy.relu and self.downsample is None and fused_eligible(self.conv1, True):
+                c1 = conv2d_fused(lazy.raw, self.conv1, in_norm=lazy.params)     # the block's input is normalised on the fly too
+            else:
+                if lazy is not None:
+                    x, lazy = lazy.materialize(), None
+                c1 = self.conv1(x)
             if self.downsample is not None:
-                x = conv_norm_act(self.downsample[0], self.norm3, x, False)
+                # the projection's norm (no ReLU) is applied inside the join
+                x = LazyNorm(self.norm3, self.downsample[0](x), relu=False) if _plain_instance_norm(self.norm3) \
+                    else conv_norm_act(self.downsample[0], self.norm3, x, False)
             c2 = conv2d_fused(c1, self.conv2, in_norm=instance_norm_params(self.norm1, c1))
             return norm_add_relu(self.norm2, x, c2)
+        if lazy is not None:
+            x = lazy.materialize()
         y = conv_norm_act(self.conv1, self.norm1, x, True)
         if self.downsample is not None:
             x = conv_norm_act(self.downsample[0], self.norm3, x, False)
@@ -243,7 +276,12 @@ class _Trunk(nn.Module):
         self.layer3 = _stage(96, 128, norm_fn, 1 + (downsample > 0))
 
     def _trunk(self, x):
-        x = conv_norm_act(self.conv1, self.norm1, x, True)
+        if FUSE_ENCODER and _plain_instance_norm(self.norm1) and _hip_ok(x):
+            # fnet: the stem's normalise + ReLU pass is folded into its two consumers (layer1.0.conv1's staging, the
+            # residual operand of layer1.0's join)
+            x = LazyNorm(self.norm1, self.conv1(x), relu=True)
+        else:
+            x = conv_norm_act(self.conv1, self.norm1, x, True)
         return self.layer3(self.layer2(self.layer1(x)))
 
 

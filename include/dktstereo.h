@@ -378,6 +378,13 @@ int dkt_instance_norm(const float *x, float *y, void *workspace, int planes, lon
 int dkt_instance_norm_stats(const float *x, void *workspace, int planes, long HW, int device, void *stream);
 int dkt_instance_norm_add_relu(const float *a, const float *c, float *y, const void *workspace,
                                int planes, long HW, float eps, int device, void *stream);
+/* dkt_instance_norm_add_relu whose residual operand `a` is itself still un-normalised (the stem output in front of
+ * the first residual block, core/extractor.py:176-178; the projection of a down-sampling block, :36-38):
+ * y = relu(a' + relu(instance_norm(c))),  a' = [relu]((a - mean_a) * invstd_a)  with (mean_a, invstd_a) per plane from
+ * dkt_instance_norm_finalize -- the normalise pass over `a` is never run. */
+int dkt_instance_norm_add_relu_lazy(const float *a, const float *a_mean_invstd /* (planes,2) */, int a_relu,
+                                    const float *c, float *y, const void *workspace, int planes, long HW, float eps,
+                                    int device, void *stream);
 /* The statistics of dkt_instance_norm_stats as (mean, 1/sqrt(var + eps)) float pairs, one per plane: the
  * `in_norm` operand of dkt_conv2d_f16s_desc, which folds relu(instance_norm(x)) between the two 3x3 layers
  * of a residual block (core/extractor.py:46-50) into the second layer's staging. */

@@ -749,3 +749,18 @@ def test_head_accumulate_epilogue():
         both = coords.clone()
         head.add_to(x, both)
         assert torch.equal(both, coords + head(x))
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("relu", [True, False])
+def test_lazy_residual_operand_of_the_instance_norm_join(relu):
+    """dkt_instance_norm_add_relu_lazy: the residual operand is normalised (and optionally rectified) inside the join --
+    the same bits as normalising it in a pass of its own first."""
+    from dkt_stereo_amd import extractor
+    norm = torch.nn.InstanceNorm2d(24)
+    a = G(_synth.normal((2, 24, 33, 52), 81, "la", scale=2.0)) + 0.4
+    c = G(_synth.normal((2, 24, 33, 52), 82, "lc", scale=3.0)) - 0.2
+    want = extractor.norm_add_relu(norm, extractor.norm_act(norm, a, relu), c)
+    got = extractor.norm_add_relu(norm, extractor.LazyNorm(norm, a, relu), c)
+    assert torch.equal(got, want)
+    assert torch.equal(extractor.LazyNorm(norm, a, relu).materialize(), extractor.norm_act(norm, a, relu))
