@@ -19,6 +19,8 @@ from .conv import _CACHE_LOCK, conv2d, conv2d_fused, fused_eligible
 
 #: DKT_FUSE_ENCODER=0: separate normalise / residual-join passes around the encoders' convolutions (A/B switch)
 FUSE_ENCODER = os.environ.get("DKT_FUSE_ENCODER", "1") != "0"
+#: DKT_CNET_STREAMS=0: the context encoder's output heads one after the other on the trunk's stream
+CNET_STREAMS = os.environ.get("DKT_CNET_STREAMS", "1") != "0"
 
 
 def _hip_ok(x):
@@ -322,19 +324,46 @@ class MultiBasicEncoder(_Trunk):
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init_like_reference(self)
 
+    def _heads_on_streams(self, x, num_layers):
+        """The output heads of the three scales beside the trunk's coarse stages: the 1/8 and 1/16 layers are a few
+        dozen tiles each -- 30 us per layer whatever their size -- and left ~0.6 ms of the pair with one such kernel at
+        a time on the device.  main: layer4 -> layer5 -> 1/16 heads; stream a: 1/4 heads; stream b: 1/8 heads."""
+        from .update import _side_stream
+        main = torch.cuda.current_stream(x.device)
+        sa, sb = _side_stream(x.device, slot=2), _side_stream(x.device, slot=3)
+        sa.wait_stream(main)
+        with torch.cuda.stream(sa):
+            s08 = [f(x) for f in self.outputs08]
+        y = self.layer4(x)
+        sb.wait_stream(main)
+        with torch.cuda.stream(sb):
+            s16 = [f(y) for f in self.outputs16]
+        scales = [s08, s16]
+        if num_layers >= 3:
+            z = self.layer5(y)
+            scales.append([f(z) for f in self.outputs32])
+        main.wait_stream(sa)
+        main.wait_stream(sb)
+        for t in s08 + s16:                      # allocated on the side streams, consumed on this one from here on
+            t.record_stream(main)
+        return scales
+
     def forward(self, x, dual_inp=False, num_layers=3):
         x = self._trunk(x)
         v = None
         if dual_inp:
             v = x
             x = x[:(x.shape[0] // 2)]
-        scales = [[f(x) for f in self.outputs08]]
-        if num_layers >= 2:
-            y = self.layer4(x)
-            scales.append([f(y) for f in self.outputs16])
-        if num_layers >= 3:
-            z = self.layer5(y)
-            scales.append([f(z) for f in self.outputs32])
+        if CNET_STREAMS and num_layers >= 2 and _hip_ok(x) and not torch.cuda.is_current_stream_capturing():
+            scales = self._heads_on_streams(x, num_layers)
+        else:
+            scales = [[f(x) for f in self.outputs08]]
+            if num_layers >= 2:
+                y = self.layer4(x)
+                scales.append([f(y) for f in self.outputs16])
+            if num_layers >= 3:
+                z = self.layer5(y)
+                scales.append([f(z) for f in self.outputs32])
         if dual_inp:
             scales.append(v)
         return tuple(scales)
