@@ -308,6 +308,14 @@ class BasicEncoder(_Trunk):
         return x
 
 
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        return [obj]
+    if isinstance(obj, (list, tuple)):
+        return [t for o in obj for t in _tensors_of(o)]
+    return []
+
+
 class MultiBasicEncoder(_Trunk):
     def __init__(self, output_dim=[128], norm_fn='batch', dropout=0.0, downsample=3):
         super().__init__()
@@ -324,7 +332,7 @@ class MultiBasicEncoder(_Trunk):
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init_like_reference(self)
 
-    def _heads_on_streams(self, x, num_layers):
+    def _heads_on_streams(self, x, num_layers, post):
         """The output heads of the three scales beside the trunk's coarse stages: the 1/8 and 1/16 layers are a few
         dozen tiles each -- 30 us per layer whatever their size -- and left ~0.6 ms of the pair with one such kernel at
         a time on the device.  main: layer4 -> layer5 -> 1/16 heads; stream a: 1/4 heads; stream b: 1/8 heads."""
@@ -333,37 +341,40 @@ class MultiBasicEncoder(_Trunk):
         sa, sb = _side_stream(x.device, slot=2), _side_stream(x.device, slot=3)
         sa.wait_stream(main)
         with torch.cuda.stream(sa):
-            s08 = [f(x) for f in self.outputs08]
+            s08 = post(0, [f(x) for f in self.outputs08])
         y = self.layer4(x)
         sb.wait_stream(main)
         with torch.cuda.stream(sb):
-            s16 = [f(y) for f in self.outputs16]
+            s16 = post(1, [f(y) for f in self.outputs16])
         scales = [s08, s16]
         if num_layers >= 3:
             z = self.layer5(y)
-            scales.append([f(z) for f in self.outputs32])
+            scales.append(post(2, [f(z) for f in self.outputs32]))
         main.wait_stream(sa)
         main.wait_stream(sb)
-        for t in s08 + s16:                      # allocated on the side streams, consumed on this one from here on
+        for t in _tensors_of(s08) + _tensors_of(s16):    # allocated on the side streams, consumed on this one from here on
             t.record_stream(main)
         return scales
 
-    def forward(self, x, dual_inp=False, num_layers=3):
+    def forward(self, x, dual_inp=False, num_layers=3, head_post=None):
+        """head_post(i, [hidden_i, context_i]) -> anything: an optional per-scale epilogue of the caller (RAFT-Stereo's tanh /
+        relu / context_zqr convolution, raft_stereo.py:103-106) that then runs on the stream of that scale's heads."""
         x = self._trunk(x)
         v = None
         if dual_inp:
             v = x
             x = x[:(x.shape[0] // 2)]
+        post = head_post if head_post is not None else (lambda i, outs: outs)
         if CNET_STREAMS and num_layers >= 2 and _hip_ok(x) and not torch.cuda.is_current_stream_capturing():
-            scales = self._heads_on_streams(x, num_layers)
+            scales = self._heads_on_streams(x, num_layers, post)
         else:
-            scales = [[f(x) for f in self.outputs08]]
+            scales = [post(0, [f(x) for f in self.outputs08])]
             if num_layers >= 2:
                 y = self.layer4(x)
-                scales.append([f(y) for f in self.outputs16])
+                scales.append(post(1, [f(y) for f in self.outputs16]))
             if num_layers >= 3:
                 z = self.layer5(y)
-                scales.append([f(z) for f in self.outputs32])
+                scales.append(post(2, [f(z) for f in self.outputs32]))
         if dual_inp:
             scales.append(v)
         return tuple(scales)

@@ -167,16 +167,22 @@ class RAFTStereo(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fmap1, fmap2 = self.fnet([image1, image2])
-            cnet_list = self.cnet(image1, num_layers=n)
+            cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
             main.wait_stream(side)
         else:
-            cnet_list = self.cnet(image1, num_layers=n)
+            cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
             fmap1, fmap2 = self.fnet([image1, image2])
-        net_list = [torch.tanh(x[0]) for x in cnet_list]
-        inp_list = [torch.relu(x[1]) for x in cnet_list]
-        inp_list = [list(conv2d(i, conv).split(split_size=conv.out_channels // 3, dim=1))
-                    for i, conv in zip(inp_list, self.context_zqr_convs)]
+        net_list = [x[0] for x in cnet_list]
+        inp_list = [x[1] for x in cnet_list]
         return fmap1.float(), fmap2.float(), net_list, inp_list
+
+    def _context_post(self, i, outs):
+        """raft_stereo.py:103-106 for scale i: tanh of the hidden head, relu + context_zqr convolution of the context
+        head (split into the cz, cr, cq operands of that scale's GRU) -- run by the context encoder on the stream of
+        the scale's heads."""
+        conv = self.context_zqr_convs[i]
+        return [torch.tanh(outs[0]),
+                list(conv2d(torch.relu(outs[1]), conv).split(split_size=conv.out_channels // 3, dim=1))]
 
     def upsample_flow(self, flow, mask):
         """raft_stereo.py:70-82, convex combination over a 3x3 neighbourhood: one fused kernel
