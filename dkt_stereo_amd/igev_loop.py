@@ -60,7 +60,8 @@ def _body(ub, st, need_mask, last):
     up_mid, pool_mid = [], []
     pair = PAIR_GRUS and not last
     with harness(inplace_state=True, side_stream=False, before_fine=lambda: main.wait_event(done_mid),
-                 fine_interp=lambda: up_mid[0], pair_coarse=pair, coarse_pool=lambda: pool_mid[0]):
+                 fine_interp=lambda: up_mid[0], pair_coarse=pair, coarse_pool=lambda: pool_mid[0],
+                 accumulate_into=st.disp):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ub(nets, st.inp, iter04=False, iter08=True, iter16=False, update=False)        # mid GRU (i)
@@ -76,7 +77,7 @@ def _body(ub, st, need_mask, last):
         geo_feat = st.geo_fn(st.disp, st.coords)
         nets, mask, delta = ub(nets, st.inp, geo_feat, st.disp, iter16=False, iter08=False, need_mask=need_mask)
         main.wait_stream(side)
-    st.disp.add_(delta)
+    assert delta is None                                 # the head added it to st.disp in its epilogue
     for dst, src in zip(st.net, nets):
         if dst is not src:
             dst.copy_(src)
@@ -190,7 +191,11 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
         st.geo_fn = geo_fn
         if cache is not None:
             geo_fn.own_buffers()                     # before the capture: changes the level-0 pointer
-        st.disp = init_disp.clone()
+        # the running disparity lives in the tail channel of the motion-feature buffer the encoder writes into
+        # (no copy for the torch.cat of igev_stereo/update.py:92)
+        b_, _, h_, w_ = init_disp.shape
+        _, st.disp = update_block.encoder.new_feature_buffer(b_, h_, w_, init_disp.device)
+        st.disp.copy_(init_disp)
         st.coords = coords.clone()
         st.net = [t.clone() for t in net_list]
         st.inp = [[t.clone() for t in scale] for scale in inp_list]

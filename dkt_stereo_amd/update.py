@@ -44,6 +44,7 @@ class _Harness(threading.local):
     pair_coarse = False       # run the coarsest GRU of the NEXT iteration in the launches of the finest GRU
     coarse_pool = None        # callable returning pool2x(net[1]) for that paired coarsest GRU
     branch_streams = False    # motion encoder's flow branch on its own stream
+    accumulate_into = None    # tensor: the head adds its result to it in its epilogue; forward() returns delta = None
 
 
 _HARNESS = _Harness()
@@ -564,6 +565,10 @@ class BasicMultiUpdateBlockIGEV(BasicMultiUpdateBlock):
                               lambda: self.encoder(disp, corr), iter04, iter08, iter16)
         if not update:
             return net
-        delta_disp = self.disp_head(net[0])
+        if _HARNESS.accumulate_into is not None:
+            self.disp_head.add_to(net[0], _HARNESS.accumulate_into)      # disp += delta in the tail layer's epilogue
+            delta_disp = None
+        else:
+            delta_disp = self.disp_head(net[0])
         mask_feat_4 = conv2d(net[0], self.mask_feat_4[0], relu=True) if need_mask else None
         return net, mask_feat_4, delta_disp
