@@ -79,6 +79,7 @@ SIGNATURES = {
                                  _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_direct": [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_direct_accumulate": [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_conv2d_direct_accumulate_diff": [_vp, _l, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_instance_norm_workspace": [_i, _l],
     "dkt_instance_norm": [_vp, _vp, _vp, _i, _l, _f, _i, _i, _vp],
     "dkt_add_relu": [_vp, _vp, _vp, _l, _i, _vp],

@@ -257,7 +257,7 @@ def _conv2d_direct(x, layer, relu, out):
     return out
 
 
-def conv2d_accumulate(x, layer, out):
+def conv2d_accumulate(x, layer, out, diff=None):
     """out += conv(x) + bias for a few-output 3x3 layer (``few_eligible``): the head layer of the refinement loop adds its
     result to the running coordinates / disparity in its epilogue (one elementwise launch less per iteration).
     `out`: (B, Cout, H, W) view, dense per batch element."""
@@ -272,6 +272,18 @@ def conv2d_accumulate(x, layer, out):
     w = layer.weight.detach()
     w = w if w.is_contiguous() else w.contiguous()
     b = layer.bias
+    if diff is not None:
+        # diff = (ref, dst): dst = out_new - ref, both shaped like `out` (dense per batch element)
+        ref, dst = diff
+        for t in (ref, dst):
+            if not _dense(t) or t.dtype != torch.float32 or tuple(t.shape) != (B, cout, H, W):
+                raise ValueError("conv2d_accumulate(diff=(ref, dst)): both must be dense-per-batch fp32 tensors shaped like out")
+        rc = _ffi.lib().dkt_conv2d_direct_accumulate_diff(
+            x.data_ptr(), x.stride(0), w.data_ptr(), None if b is None else b.data_ptr(), out.data_ptr(), out.stride(0),
+            ref.data_ptr(), ref.stride(0), dst.data_ptr(), dst.stride(0), B, cin, cout, H, W, kh, kw,
+            _ffi.device_of(x), _ffi.stream_of(x))
+        _ffi.check(rc, "dkt_conv2d_direct_accumulate_diff")
+        return out
     rc = _ffi.lib().dkt_conv2d_direct_accumulate(x.data_ptr(), x.stride(0), w.data_ptr(), None if b is None else b.data_ptr(),
                                                  out.data_ptr(), out.stride(0), B, cin, cout, H, W, kh, kw,
                                                  _ffi.device_of(x), _ffi.stream_of(x))

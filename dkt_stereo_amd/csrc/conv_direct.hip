@@ -19,6 +19,9 @@ struct DirectArgs {
     int Cin, Cout, H, W, tiles_w;
     int relu;
     int accumulate;      // few-output 3x3 form only: y += result (the loop's coords1 += delta in the head's epilogue)
+    const float *diff_ref;   // ... and, optionally, diff_out = y_new - diff_ref (the loop's flow = coords1 - coords0)
+    float *diff_out;
+    long diff_ref_bs, diff_out_bs;
 };
 
 // Thread = 4 horizontally adjacent pixels x TO output channels (register blocking: the 4 + 2*HALO
@@ -268,7 +271,12 @@ __global__ __launch_bounds__(64 * FEW_NW) void conv3x3_few_kernel(DirectArgs a) 
             for (int ww = 1; ww < FEW_NW; ++ww) v = __fadd_rn(v, part[((ww * TO + o) * 4 + p) * 64 + lane]);
             v = __fadd_rn(v, bias);
             if (a.relu) v = dkt_relu(v);
-            yr[p] = a.accumulate ? __fadd_rn(yr[p], v) : v;
+            v = a.accumulate ? __fadd_rn(yr[p], v) : v;
+            yr[p] = v;
+            if (a.diff_out) {
+                const long off = (long)o * HW + (long)oh * a.W + w0 + q4 + p;
+                a.diff_out[(long)b * a.diff_out_bs + off] = __fsub_rn(v, a.diff_ref[(long)b * a.diff_ref_bs + off]);
+            }
         }
     }
 }
@@ -304,7 +312,8 @@ static int launch_direct(const DirectArgs &a, int B, hipStream_t st) {
 
 static int conv2d_direct_impl(const float *x, long x_bstride, const float *w, const float *bias,
                               float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
-                              int KH, int KW, int relu, int accumulate, int device, void *stream);
+                              int KH, int KW, int relu, int accumulate, int device, void *stream,
+                              const float *diff_ref = nullptr, long diff_ref_bs = 0, float *diff_out = nullptr, long diff_out_bs = 0);
 
 extern "C" int dkt_conv2d_direct(const float *x, long x_bstride, const float *w, const float *bias,
                                  float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
@@ -319,9 +328,20 @@ extern "C" int dkt_conv2d_direct_accumulate(const float *x, long x_bstride, cons
     return conv2d_direct_impl(x, x_bstride, w, bias, y, y_bstride, B, Cin, Cout, H, W, KH, KW, 0, 1, device, stream);
 }
 
+extern "C" int dkt_conv2d_direct_accumulate_diff(const float *x, long x_bstride, const float *w, const float *bias,
+                                                 float *y, long y_bstride, const float *diff_ref, long diff_ref_bstride,
+                                                 float *diff_out, long diff_out_bstride, int B, int Cin, int Cout,
+                                                 int H, int W, int KH, int KW, int device, void *stream) {
+    if (KH != 3 || Cout > 4) return DKT_E_UNSUPPORTED;
+    if (!diff_ref || !diff_out) return DKT_E_NULL;
+    return conv2d_direct_impl(x, x_bstride, w, bias, y, y_bstride, B, Cin, Cout, H, W, KH, KW, 0, 1, device, stream,
+                              diff_ref, diff_ref_bstride, diff_out, diff_out_bstride);
+}
+
 static int conv2d_direct_impl(const float *x, long x_bstride, const float *w, const float *bias,
                               float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
-                              int KH, int KW, int relu, int accumulate, int device, void *stream) {
+                              int KH, int KW, int relu, int accumulate, int device, void *stream,
+                              const float *diff_ref, long diff_ref_bs, float *diff_out, long diff_out_bs) {
     if (!x || !w || !y) return DKT_E_NULL;
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || B > 65535) return DKT_E_SHAPE;
     if (KH != KW || (KH != 3 && KH != 7)) return DKT_E_UNSUPPORTED;
@@ -330,6 +350,7 @@ static int conv2d_direct_impl(const float *x, long x_bstride, const float *w, co
     a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.tiles_w = (W + 63) / 64;
     a.relu = relu ? 1 : 0;
     a.accumulate = accumulate ? 1 : 0;
+    a.diff_ref = diff_ref; a.diff_out = diff_out; a.diff_ref_bs = diff_ref_bs; a.diff_out_bs = diff_out_bs;
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
     if (KH == 3) {

@@ -331,16 +331,19 @@ class RAFTStereo(nn.Module):
         hold["up16"] = interp(nets[1], nets[0])          # gru08's operand (core/update.py:127)
         hold["pool16"] = pool2x(nets[1])                 # gru32's operand (core/update.py:119)
 
-    def _stage_motion(self, corr_fn, coords0, coords1):
+    def _stage_motion(self, corr_fn, coords0, coords1, flow=None):
         enc = self.update_block.encoder
         corr = self._lookup(corr_fn, coords1)
         if hasattr(corr, "materialize"):
             corr = _Precomputed(enc._cor1(corr))
-        # the flow is computed straight into the tail channels of the motion-feature buffer (no copy for the torch.cat
-        # of core/update.py:85)
-        b, _, h, w = coords1.shape
-        _, flow = enc.new_feature_buffer(b, h, w, coords1.device)
-        torch.sub(coords1, coords0, out=flow)
+        if flow is None:
+            # the flow is computed straight into the tail channels of the motion-feature buffer (no copy for the
+            # torch.cat of core/update.py:85)
+            b, _, h, w = coords1.shape
+            _, flow = enc.new_feature_buffer(b, h, w, coords1.device)
+            torch.sub(coords1, coords0, out=flow)
+        # else: `flow` is the tail of the loop's persistent feature buffer, kept equal to coords1 - coords0 by the
+        # head's epilogue (_stage_head)
         return enc(flow, corr)
 
     def _stage_fine(self, nets, inp, mf, hold):
@@ -352,14 +355,18 @@ class RAFTStereo(nn.Module):
     #: the rotated loop computes only the x output of flow_head.conv2 (DKT_HEAD_X_ONLY=0: both, y dropped afterwards)
     head_x_only = os.environ.get("DKT_HEAD_X_ONLY", "1") != "0"
 
-    def _stage_head(self, nets, coords1, need_mask):
+    def _stage_head(self, nets, coords1, need_mask, coords0=None, flow=None):
         ub = self.update_block
         if self.head_x_only:
-            # stereo: only x moves (raft_stereo.py:165-168) -- the y output is not computed, and the x output is added
-            # to coords1 in the tail layer's epilogue
-            ub.flow_head.add_to(nets[0], coords1[:, :1], outputs=1)
+            # stereo: only x moves (raft_stereo.py:165-168) -- the y output is not computed, the x output is added to
+            # coords1 in the tail layer's epilogue, and the same epilogue refreshes flow_x = coords1_x - coords0_x in the
+            # persistent feature buffer (the y plane never changes)
+            diff = None if flow is None else (coords0[:, :1], flow[:, :1])
+            ub.flow_head.add_to(nets[0], coords1[:, :1], outputs=1, diff=diff)
         else:
             coords1[:, :1].add_(ub.flow_head(nets[0])[:, :1])
+            if flow is not None:
+                torch.sub(coords1, coords0, out=flow)
         mask = None
         if need_mask:
             mask = .25 * conv2d(conv2d(nets[0], ub.mask[0], relu=True), ub.mask[2])
@@ -380,8 +387,8 @@ class RAFTStereo(nn.Module):
                     for t in hold.values():
                         t.record_stream(main)
                 done.record(side)
-            self._stage_head(nets, st["coords1"], False)
-            mf = self._stage_motion(st["corr"], st["coords0"], st["coords1"])
+            self._stage_head(nets, st["coords1"], False, st["coords0"], st["flow"])
+            mf = self._stage_motion(st["corr"], st["coords0"], st["coords1"], st["flow"])
             main.wait_event(done)                        # join
             main.wait_stream(side)
             self._stage_fine(nets, st["inp"], mf, hold)
@@ -390,10 +397,14 @@ class RAFTStereo(nn.Module):
         """Prologue: gru32(0), gru16(0), lookup + motion encoder(0), gru08(0) + gru32(1).  Then iters-1 rotated
         units (the first eagerly, one captured, the rest replayed), then the last flow head with the mask."""
         nets, hold = st["net"], {}
+        if "flow" not in st:                 # persistent motion-feature buffer; its tail holds flow = coords1 - coords0
+            b, _, h, w = st["coords1"].shape
+            st["feat"], st["flow"] = self.update_block.encoder.new_feature_buffer(b, h, w, st["coords1"].device)
+        torch.sub(st["coords1"], st["coords0"], out=st["flow"])          # both planes once per pair (covers flow_init)
         with harness(inplace_state=True, side_stream=False):
             self.update_block(nets, st["inp"], iter32=True, iter16=False, iter08=False, update=False)
             self._stage_mid(nets, st["inp"], hold)
-            mf = self._stage_motion(st["corr"], st["coords0"], st["coords1"])
+            mf = self._stage_motion(st["corr"], st["coords0"], st["coords1"], st["flow"])
             self._stage_fine(nets, st["inp"], mf, hold)
         done = 0
         if st["graph"] is None:
@@ -407,7 +418,7 @@ class RAFTStereo(nn.Module):
         for _ in range(iters - 1 - done):
             replay_graph(st["graph"])
         with harness(inplace_state=True, side_stream=False):
-            return self._stage_head(nets, st["coords1"], True)
+            return self._stage_head(nets, st["coords1"], True, st["coords0"], st["flow"])
 
     def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init):
         """Same arithmetic as the eager loop; iterations 2..iters-1 are replays of one

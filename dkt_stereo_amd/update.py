@@ -160,14 +160,18 @@ class FlowHead(nn.Module):
         head = self.conv2 if outputs is None or outputs >= self.conv2.out_channels else _leading_outputs(self.conv2, outputs)
         return conv2d(conv2d(x, self.conv1, relu=True), head)
 
-    def add_to(self, x, target, outputs=None):
+    def add_to(self, x, target, outputs=None, diff=None):
         """target += head(x) in the tail layer's epilogue when it runs on the few-output kernel (else the plain add).
-        `target`: (B, outputs, H, W) view of the running coordinates / disparity."""
+        `target`: (B, outputs, H, W) view of the running coordinates / disparity.  diff = (ref, dst): also
+        dst = target_new - ref (the next iteration's flow = coords1 - coords0) in the same epilogue."""
         head = self.conv2 if outputs is None or outputs >= self.conv2.out_channels else _leading_outputs(self.conv2, outputs)
         hidden = conv2d(x, self.conv1, relu=True)
         if few_eligible(head) and target.is_cuda:
-            return conv2d_accumulate(hidden, head, target)
-        return target.add_(conv2d(hidden, head))
+            return conv2d_accumulate(hidden, head, target, diff=diff)
+        target.add_(conv2d(hidden, head))
+        if diff is not None:
+            torch.sub(target, diff[0], out=diff[1])
+        return target
 
 
 class _LayerView:

@@ -355,6 +355,12 @@ int dkt_conv2d_direct(const float *x, long x_bstride, const float *w, const floa
 int dkt_conv2d_direct_accumulate(const float *x, long x_bstride, const float *w, const float *bias,
                                  float *y, long y_bstride, int B, int Cin, int Cout, int H, int W,
                                  int KH, int KW, int device, void *stream);
+/* ... and diff_out = y_new - diff_ref on top (planes shaped like y): the flow operand of the next iteration's motion
+ * encoder, flow = coords1 - coords0 (raft_stereo.py:147), written by the same epilogue. */
+int dkt_conv2d_direct_accumulate_diff(const float *x, long x_bstride, const float *w, const float *bias,
+                                      float *y, long y_bstride, const float *diff_ref, long diff_ref_bstride,
+                                      float *diff_out, long diff_out_bstride, int B, int Cin, int Cout,
+                                      int H, int W, int KH, int KW, int device, void *stream);
 
 /* ---- streaming helpers around the convolutions ---------------------------------------- */
 

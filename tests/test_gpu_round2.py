@@ -749,6 +749,13 @@ def test_head_accumulate_epilogue():
         both = coords.clone()
         head.add_to(x, both)
         assert torch.equal(both, coords + head(x))
+        # ... with the flow refresh (dst = target_new - ref) in the same epilogue, into a channel slice of a wider buffer
+        ref = G(_synth.normal((2, 2, 30, 52), 73, "c0", scale=20.0))
+        feat = torch.full((2, 6, 30, 52), 5.0, device=DEV)
+        got = coords.clone()
+        head.add_to(x, got[:, :1], outputs=1, diff=(ref[:, :1], feat[:, 4:5]))
+        assert torch.equal(got, want) and torch.equal(feat[:, 4:5], want[:, :1] - ref[:, :1])
+        assert float(feat[:, :4].min()) == 5.0 and float(feat[:, 5:].max()) == 5.0
 
 
 @torch.no_grad()
