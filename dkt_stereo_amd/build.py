@@ -17,6 +17,11 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
           "-Wno-pass-failed"]
 FLAGS = CFLAGS + ["-shared"]       # single-command form: hipcc FLAGS csrc/*.hip -o libdktstereo.so
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
+# Per-source flags.  conv_direct: no SLP vectorisation, i.e. scalar v_fma_f32 instead of v_pk_fma_f32 chains -- the
+# SLP build of conv3x3_few_kernel returned wrong low halves of its packed accumulators (lanes 48..63) whenever its
+# block shared a CU with a block of the MFMA convolution (tools/stress_lds_dma.py: 1000/1200 launches wrong
+# with packed math, 0/1200 with scalar math under the same co-residency).
+EXTRA_FLAGS = {"conv_direct": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -45,7 +50,7 @@ def build(force=False, verbose=False):
             for tu in (0, 1, 2, 3):
                 jobs.append((src, os.path.join(OBJ_DIR, "conv2d_tu%d.o" % tu), ["-DCONV_TU_PASSES=%d" % tu]))
         else:
-            jobs.append((src, os.path.join(OBJ_DIR, stem + ".o"), []))
+            jobs.append((src, os.path.join(OBJ_DIR, stem + ".o"), EXTRA_FLAGS.get(stem, [])))
 
     def compile_one(job):
         src, obj, extra = job

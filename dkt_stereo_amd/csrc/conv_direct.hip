@@ -138,6 +138,18 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(DirectArgs a) {
 //            is one 16-byte and two 4-byte LDS reads per lane;
 //   the eight channel slices are summed through LDS in wave order, bias / ReLU in the epilogue.
 // ---------------------------------------------------------------------------------------------------------
+#if defined(FEW_DEBUG) || defined(FEW_DEBUG2)
+// tools/stress_lds_dma.py instrumentation (never in the product build): [0] DMA'd 16-byte groups that differ from
+// global memory, [1..5] LDS_ALLOC / wave / chunk / piece / lane of the first one, [6] weight words that differ,
+// [7] masked groups that are not zero, [8] blocks with LDS base != 0, [9] blocks, [10] mismatching groups found
+// intact 1 KiB further / [11] elsewhere in the wave's buffers
+__device__ int few_dbg[16];
+extern "C" int dkt_debug_few_counters(int *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(few_dbg), sizeof(int) * 16) != hipSuccess) return -1;
+    if (reset) { int z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(few_dbg), z, sizeof z); }
+    return 0;
+}
+#endif
 #define FEW_CC 4
 #define FEW_NW 8                                    // waves per block = channel slices
 #define FEW_PR 6
@@ -213,10 +225,55 @@ __global__ __launch_bounds__(64 * FEW_NW) void conv3x3_few_kernel(DirectArgs a) 
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int o = 0; o < TO; ++o) acc[p][o] = 0.0f;
+#ifdef FEW_DEBUG2
+    unsigned dbg_bad = 0;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the zero fill has landed before the first DMA
     if (nchunk > 0) stage(0, 0);
     for (int k = 0; k < nchunk; ++k) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // chunk k is in LDS
+#ifdef FEW_DEBUG
+        if (vec) {
+            const float *chk = mybuf + (k & 1) * BUF;
+            for (int c = 0; c < FEW_CC; ++c) {
+                const int ch = c_lo + k * FEW_CC + c;
+                if (ch >= c_hi) break;
+                const float *xc = xb + (long)ch * HW;
+                for (int j = 0; j < 2; ++j) {
+                    const int g = 64 * j + lane;
+                    if (g >= FEW_PR * 18) continue;
+                    const float4 l4 = *(const float4 *)(chk + c * PLANE + 256 * j + lane * 4);
+                    if (g_ok[j]) {
+                        const float4 g4 = *(const float4 *)(xc + g_off[j]);
+                        if (l4.x != g4.x || l4.y != g4.y || l4.z != g4.z || l4.w != g4.w) {
+                            if (atomicAdd(&few_dbg[0], 1) == 0) {
+                                few_dbg[1] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11));
+                                few_dbg[2] = wave; few_dbg[3] = k; few_dbg[4] = c * 2 + j; few_dbg[5] = lane;
+                            }
+                            // did the group land somewhere else in this wave's two buffers?
+                            bool found = false;
+                            for (int q = 0; q < 2 * BUF / 4 && !found; ++q) {
+                                const float4 t = ((const float4 *)mybuf)[q];
+                                if (t.x == g4.x && t.y == g4.y && t.z == g4.z && t.w == g4.w && (g4.x != 0.f || g4.y != 0.f)) found = true;
+                            }
+                            atomicAdd(&few_dbg[found ? 11 : 10], 1);
+                        }
+                    } else if (l4.x != 0.f || l4.y != 0.f || l4.z != 0.f || l4.w != 0.f) atomicAdd(&few_dbg[7], 1);
+                }
+            }
+        }
+        if (k == 0) {
+            for (int i = lane; i < (c_hi - c_lo) * TO * 9; i += 64) {
+                const int t = i % 9, o = (i / 9) % TO, c = i / (9 * TO);
+                const float e = o < a.Cout ? a.w[((long)o * a.Cin + c_lo + c) * 9 + t] : 0.0f;
+                if (wl[(c * TO + o) * 12 + t] != e) atomicAdd(&few_dbg[6], 1);
+            }
+            if (tid == 0) {
+                atomicAdd(&few_dbg[9], 1);
+                if (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11)) & 0xfff) atomicAdd(&few_dbg[8], 1);
+            }
+        }
+#endif
         if (k + 1 < nchunk) stage(k + 1, (k + 1) & 1);             // chunk k+1 streams in under the FMAs of chunk k
         const float *src = mybuf + (k & 1) * BUF;
 #pragma unroll
@@ -238,6 +295,17 @@ __global__ __launch_bounds__(64 * FEW_NW) void conv3x3_few_kernel(DirectArgs a) 
                 const float *pr = src + c * PLANE + (prow + dy) * FEW_PCP + q4 + 4;
                 const float4 v4 = *(const float4 *)pr;
                 const float v[6] = {pr[-1], v4.x, v4.y, v4.z, v4.w, pr[4]};
+#ifdef FEW_DEBUG2
+                if (dy == 2) {   // light check (keeps the VGPR count of the product): patch rows 2..5 as read vs global memory
+                    const int ih = h0 - 1 + prow + dy;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        const int iw = w0 + q4 - 1 + e;
+                        const float g = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? xb[(long)ch * HW + (long)ih * a.W + iw] : 0.0f;
+                        dbg_bad |= (g != v[e]) ? (1u << e) : 0u;
+                    }
+                }
+#endif
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -247,6 +315,12 @@ __global__ __launch_bounds__(64 * FEW_NW) void conv3x3_few_kernel(DirectArgs a) 
             }
         }
     }
+#ifdef FEW_DEBUG2
+    if (dbg_bad) {
+        if (atomicAdd(&few_dbg[12], 1) == 0) { few_dbg[13] = (lane << 16) | (dbg_bad << 4) | wave; few_dbg[14] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11)); }
+    }
+    if (tid == 0) { atomicAdd(&few_dbg[9], 1); if (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (31 << 11)) & 0xfff) atomicAdd(&few_dbg[8], 1); }
+#endif
     // ---- sum the four channel quarters (wave order), bias, ReLU, store
     __syncthreads();
     float *part = few_lds;                                           // [FEW_NW waves][TO][4 px][64 lanes]
@@ -286,13 +360,19 @@ static int launch_few(DirectArgs a, int B, hipStream_t st) {
     const int cq = (a.Cin + FEW_NW - 1) / FEW_NW;
     const size_t need = ((size_t)FEW_NW * 2 * FEW_CC * FEW_PR * FEW_PCP + (size_t)FEW_NW * cq * TO * 12) * sizeof(float);
     if (need > 160 * 1024) return DKT_E_UNSUPPORTED;
-    // The block always asks for the CU's WHOLE LDS (160 KB), whatever it needs.  Measured on MI355X / ROCm 7.2: when a
-    // block of ANOTHER kernel that holds LDS is resident on the same CU (the TO = 1 form needs 123 KB, which leaves room
-    // for a 33 KB block of the 1/16-resolution GRU convolution running on the second stream), the global_load_lds
-    // copies of this kernel do not arrive in its buffers -- 1000 of 1200 launches wrong in tools/stress_lds_dma.py, the
-    // co-resident kernel's results intact -- while the same launches are exact whenever the block has the CU's LDS to
-    // itself (allocation base 0).  Taking all of it makes that the only case.
-    const size_t lds = 160 * 1024;
+    // The block asks for the CU's WHOLE LDS (160 KB), whatever it needs, so that no LDS-holding block of another kernel
+    // shares its CU.  History: the TO = 1 form needs 120 KB, which leaves room for a 33 KB block of the
+    // 1/16-resolution GRU convolution on the second stream, and in that situation the SLP-vectorised build of this
+    // kernel (v_pk_fma_f32 chains) returned wrong sums -- 1000 of 1200 launches in tools/stress_lds_dma.py.  Round 3
+    // established that the LDS-DMA copies are NOT at fault (every copied 16-byte group verified in place under the
+    // failing co-residency; tools/lds_dma_probe*.hip: exact for every size / offset / allocation base); the wrong
+    // values are the low halves of the packed accumulator pairs in lanes 48..63, and the scalar-FMA build
+    // (-fno-slp-vectorize, dkt_stereo_amd/build.py) is exact in 1200 of 1200 launches beside 5000+ co-resident blocks.
+    // The file is therefore built without SLP vectorisation AND the exclusive LDS claim stays as a second protection
+    // (kernels on different streams do not overlap usefully on this part anyway, tools/concurrency_probe.py).
+    // DKT_FEW_LDS_EXACT=1 (tools/stress_lds_dma.py only): request just `need`, i.e. allow LDS-holding co-residents
+    static const bool exact = [] { const char *e = getenv("DKT_FEW_LDS_EXACT"); return e && atoi(e) != 0; }();
+    const size_t lds = exact ? need : 160 * 1024;
     auto kern = conv3x3_few_kernel<TO>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
