@@ -32,8 +32,34 @@ class ConvDesc(ctypes.Structure):
                 ("in_norm", ctypes.c_void_p)]
 
 
+class ConvC8Desc(ctypes.Structure):
+    """dkt_conv_c8_desc of include/dktstereo.h."""
+    _fields_ = [("src", ctypes.c_void_p * 4), ("src_bstride", ctypes.c_long * 4), ("src_channels", ctypes.c_int * 4),
+                ("nsrc", ctypes.c_int), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("out_scale", ctypes.c_float), ("act_scale", ctypes.c_float),
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cout", ctypes.c_int), ("relu", ctypes.c_int),
+                ("epilogue", ctypes.c_int), ("out", ctypes.c_void_p), ("out_bstride", ctypes.c_long),
+                ("out_c8", ctypes.c_void_p), ("out_c8_bstride", ctypes.c_long), ("out_c8_ch0", ctypes.c_int),
+                ("e0", ctypes.c_void_p), ("e0_bstride", ctypes.c_long), ("e1", ctypes.c_void_p), ("e1_bstride", ctypes.c_long),
+                ("h", ctypes.c_void_p), ("h_bstride", ctypes.c_long), ("out2", ctypes.c_void_p), ("out2_bstride", ctypes.c_long),
+                ("out2_c8", ctypes.c_void_p), ("out2_c8_bstride", ctypes.c_long), ("out2_c8_ch0", ctypes.c_int),
+                ("tail", ctypes.c_void_p), ("tail_bstride", ctypes.c_long), ("tail_channels", ctypes.c_int),
+                ("f32_c4", ctypes.c_int)]
+
+
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
+    "dkt_pool2x_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "dkt_interp_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "dkt_conv2d_stem7_c8": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_corr1d_lookup_conv1x1_c8": [_pp, _vp, _l, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_act_c8_dims": [_i, _i, _ip, _ip],
+    "dkt_act_c8_pack": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "dkt_act_c8_unpack": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "dkt_conv_c8_packed_bytes": [_ip, _i, _i],
+    "dkt_conv_c8_pack_weights": [_vp, _ip, _i, _i, _f, _vp, _i, _vp],
+    "dkt_conv2d_c8": [ctypes.POINTER(ConvC8Desc), _i, _i, _vp],
+    "dkt_conv2d_c8_pair": [ctypes.POINTER(ConvC8Desc), ctypes.POINTER(ConvC8Desc), _i, _i, _vp],
     "dkt_conv2d_f16s_pair": [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _i, _i, _vp],
     "dkt_conv2d_f16s_desc": [ctypes.POINTER(ConvDesc), _i, _i, _vp],
     "dkt_corr1d_build": [_vp, _vp, _pp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -87,7 +113,7 @@ SIGNATURES = {
     "dkt_interp_bilinear": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
 }
 #: entry points that do not return an int status
-RESTYPES = {"dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
+RESTYPES = {"dkt_conv_c8_packed_bytes": ctypes.c_long, "dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
 
 _lib = None
 

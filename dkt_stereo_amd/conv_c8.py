@@ -1,0 +1,233 @@
+"""The 3x3 convolutions of the update operator on pre-split activations (csrc/conv_c8.hip).
+
+``ActC8`` is a "C8S" activation tensor: fp16 (hi, lo) pairs, ``[B][2*ceil(C/16)][2][Hp][Wp][8]`` with a zero border
+(include/dktstereo.h).  Producers write it from their epilogues (``conv2d_c8(..., out_c8=...)``, the resampling kernels);
+``pack`` / ``unpack`` convert from / to fp32 NCHW for glue and tests.  Reference operators: ConvGRU
+(core/update.py:16-32), BasicMotionEncoder (:64-85), FlowHead.conv1 (:9)."""
+import ctypes
+import math
+
+import torch
+
+from . import _ffi
+from .conv import _CACHE_LOCK
+
+
+def c8_dims(H, W):
+    return (H + 7) // 8 * 8 + 2, (W + 31) // 32 * 32 + 2
+
+
+class ActC8:
+    """A C8S activation tensor.  ``t``: fp16 storage (B, G, 2, Hp, Wp, 8), zero outside the written interior."""
+    __slots__ = ("t", "C", "H", "W", "scale")
+
+    def __init__(self, B, C, H, W, device, scale=1.0):
+        Hp, Wp = c8_dims(H, W)
+        self.t = torch.zeros((B, 2 * ((C + 15) // 16), 2, Hp, Wp, 8), device=device, dtype=torch.float16)
+        self.C, self.H, self.W, self.scale = C, H, W, float(scale)
+
+    @property
+    def B(self):
+        return self.t.shape[0]
+
+    @property
+    def bstride_bytes(self):
+        return self.t.stride(0) * 2
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    @property
+    def device(self):
+        return self.t.device
+
+
+def pack(x, dst=None, ch0=0, scale=None):
+    """fp32 NCHW -> channels [ch0, ch0 + C) of an ActC8 (a new one of exactly C channels by default)."""
+    _ffi.require_gpu(x)
+    B, C, H, W = x.shape
+    if dst is None:
+        dst = ActC8(B, C, H, W, x.device, 1.0 if scale is None else scale)
+    x = x if (x.stride(3) == 1 and x.stride(2) == W and x.stride(1) == H * W) else x.contiguous()
+    rc = _ffi.lib().dkt_act_c8_pack(x.data_ptr(), x.stride(0), dst.data_ptr(), dst.bstride_bytes, B, C, H, W, ch0,
+                                    dst.scale, _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_act_c8_pack")
+    return dst
+
+
+def unpack(a, C=None, ch0=0):
+    C = a.C - ch0 if C is None else C
+    y = torch.empty((a.B, C, a.H, a.W), device=a.device, dtype=torch.float32)
+    rc = _ffi.lib().dkt_act_c8_unpack(a.data_ptr(), a.bstride_bytes, y.data_ptr(), y.stride(0), a.B, C, a.H, a.W, ch0,
+                                      a.scale, _ffi.device_of(y), _ffi.stream_of(y))
+    _ffi.check(rc, "dkt_act_c8_unpack")
+    return y
+
+
+class _PackedC8:
+    __slots__ = ("key", "img", "inv_scale", "bias")
+
+
+def packed_weights(layer, src_channels):
+    """Step images of `layer` for dkt_conv2d_c8, cached on the layer per device and operand split."""
+    with _CACHE_LOCK:
+        w, b = layer.weight, layer.bias
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(src_channels))
+        cache = layer.__dict__.setdefault("_dkt_packed_c8", {})
+        slot = (str(w.device), tuple(src_channels))
+        hit = cache.get(slot)
+        if hit is not None and hit.key == key:
+            return hit
+        cout, cin, kh, kw = w.shape
+        if (kh, kw) != (3, 3) or cin != sum(src_channels):
+            raise ValueError("conv2d_c8: 3x3 layers only, operands carry %d channels, layer expects %d" % (sum(src_channels), cin))
+        L = _ffi.lib()
+        n = len(src_channels)
+        ch = (ctypes.c_int * n)(*src_channels)
+        nbytes = L.dkt_conv_c8_packed_bytes(ch, n, cout)
+        if nbytes <= 0:
+            raise _ffi.DktError("dkt_conv_c8_packed_bytes rejected the layer shape")
+        wmax = float(w.detach().abs().max())
+        e = 12 - math.floor(math.log2(wmax)) if wmax > 0 else 0       # max|w| in [2^12, 2^13): w_lo stays normal
+        p = _PackedC8()
+        p.img = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+        wc = w.detach().float().contiguous()
+        rc = L.dkt_conv_c8_pack_weights(wc.data_ptr(), ch, n, cout, 2.0 ** e, p.img.data_ptr(), _ffi.device_of(w), _ffi.stream_of(w))
+        _ffi.check(rc, "dkt_conv_c8_pack_weights")
+        p.inv_scale = 2.0 ** -e
+        p.bias = None if b is None else b.detach().float().contiguous()
+        p.key = key
+        cache[slot] = p
+        return p
+
+
+def to_c4(x):
+    """fp32 NCHW -> the "C4" layout [B][ceil(C/4)][H][W][4] of the epilogue-side tensors (gate operands, state, z)."""
+    B, C, H, W = x.shape
+    if C % 4:
+        x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 4 - C % 4))
+    return x.view(B, -1, 4, H, W).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def from_c4(x, C=None):
+    B, G, H, W, _ = x.shape
+    y = x.permute(0, 1, 4, 2, 3).reshape(B, G * 4, H, W)
+    return y if C is None or C == G * 4 else y[:, :C]
+
+
+def desc(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, epilogue=0, e0=None, e1=None, h=None,
+         out2=None, out2_c8=None, out2_c8_ch0=0, tail=None, f32_c4=False):
+    """dkt_conv_c8_desc; keeps its tensors alive through the returned object."""
+    srcs = list(srcs)
+    s0 = srcs[0]
+    for s in srcs:
+        if (s.H, s.W, s.B) != (s0.H, s0.W, s0.B) or s.scale != s0.scale:
+            raise ValueError("conv2d_c8: operands must share batch, size and activation scale")
+    pk = packed_weights(layer, [s.C for s in srcs])
+    d = _ffi.ConvC8Desc()
+    for i, s in enumerate(srcs):
+        d.src[i] = s.data_ptr()
+        d.src_bstride[i] = s.bstride_bytes
+        d.src_channels[i] = s.C
+    d.nsrc = len(srcs)
+    d.w = pk.img.data_ptr()
+    d.bias = None if pk.bias is None else pk.bias.data_ptr()
+    d.out_scale = pk.inv_scale / s0.scale
+    d.act_scale = 1.0
+    d.B, d.H, d.W, d.Cout, d.relu = s0.B, s0.H, s0.W, int(layer.weight.shape[0]), int(bool(relu))
+    d.epilogue = epilogue
+    if out is not None:
+        d.out, d.out_bstride = out.data_ptr(), out.stride(0)
+    for name, a, c0 in (("out_c8", out_c8, out_c8_ch0), ("out2_c8", out2_c8, out2_c8_ch0)):
+        if a is not None:
+            if (a.H, a.W, a.B) != (s0.H, s0.W, s0.B):
+                raise ValueError("conv2d_c8: C8S destination of another size")
+            setattr(d, name, a.data_ptr())
+            setattr(d, name + "_bstride", a.bstride_bytes)
+            setattr(d, name + "_ch0", c0)
+            d.act_scale = a.scale
+    for name, t in (("e0", e0), ("e1", e1), ("h", h), ("out2", out2), ("tail", tail)):
+        if t is not None:
+            setattr(d, name, t.data_ptr())
+            setattr(d, name + "_bstride", t.stride(0))
+    if tail is not None:
+        d.tail_channels = int(tail.shape[1])
+    d.f32_c4 = int(bool(f32_c4))
+    d._keep = (srcs, pk, out, out_c8, e0, e1, h, out2, out2_c8, tail)
+    return d
+
+
+def launch(d, ref, cfg=0):
+    rc = _ffi.lib().dkt_conv2d_c8(ctypes.byref(d), cfg, _ffi.device_of(ref), _ffi.stream_of(ref))
+    _ffi.check(rc, "dkt_conv2d_c8")
+
+
+def launch_pair(d0, d1, ref, cfg):
+    rc = _ffi.lib().dkt_conv2d_c8_pair(ctypes.byref(d0), ctypes.byref(d1), cfg, _ffi.device_of(ref), _ffi.stream_of(ref))
+    _ffi.check(rc, "dkt_conv2d_c8_pair")
+
+
+def conv2d_c8(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, tail=None, cfg=0):
+    """conv(torch.cat(srcs)) + bias [ReLU] -> fp32 NCHW `out` (allocated when neither destination is given) and / or
+    channels [out_c8_ch0, ...) of the ActC8 `out_c8`; `tail`: fp32 NCHW channels appended behind the result in
+    `out_c8` (the reference's torch.cat([out, flow]), core/update.py:85)."""
+    s0 = srcs[0]
+    if out is None and out_c8 is None:
+        out = torch.empty((s0.B, int(layer.weight.shape[0]), s0.H, s0.W), device=s0.device, dtype=torch.float32)
+    d = desc(srcs, layer, relu=relu, out=out, out_c8=out_c8, out_c8_ch0=out_c8_ch0, tail=tail)
+    launch(d, s0.t, cfg)
+    return out if out is not None else out_c8
+
+
+def gate_zr(srcs, zr_layer, cz, cr, h, rh_c8=None, rh=None, cfg=0, f32_c4=False):
+    """ConvGRU first stage (core/update.py:27-29): z = sigmoid(convz(hx)+cz) as fp32 NCHW, r*h into the ActC8 `rh_c8`
+    (the q convolution's operand) and / or the fp32 tensor `rh`."""
+    s0 = srcs[0]
+    ch = int(zr_layer.weight.shape[0]) // 2
+    z = torch.empty_like(h) if f32_c4 else torch.empty((s0.B, ch, s0.H, s0.W), device=s0.device, dtype=torch.float32)
+    d = desc(srcs, zr_layer, out=z, epilogue=1, e0=cz, e1=cr, h=h, out2=rh, out2_c8=rh_c8, f32_c4=f32_c4)
+    launch(d, z, cfg)
+    return z
+
+
+def gate_out(srcs, q_layer, cq, z, h, out, out_c8=None, cfg=0, f32_c4=False):
+    """ConvGRU second stage (core/update.py:30-31): h' = (1-z) h + z tanh(convq(rhx)+cq) -> `out` (may be h) and `out_c8`."""
+    d = desc(srcs, q_layer, out=out, out_c8=out_c8, epilogue=2, e0=cq, e1=z, h=h, f32_c4=f32_c4)
+    launch(d, out, cfg)
+    return out
+
+
+def pool2x_c8(x, dst, ch0=0):
+    """dst[ch0 : ch0 + C] = C8S(avg_pool2d(x, 3, stride=2, padding=1)) (core/update.py:87-88), x fp32 NCHW dense per batch."""
+    B, C, H, W = x.shape
+    rc = _ffi.lib().dkt_pool2x_c8(x.data_ptr(), x.stride(0), dst.data_ptr(), dst.bstride_bytes, B, C, H, W, ch0, dst.scale,
+                                  _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_pool2x_c8")
+    return dst
+
+
+def interp_c8(x, dst, ch0=0):
+    """dst[ch0 : ch0 + C] = C8S(F.interpolate(x, (dst.H, dst.W), mode="bilinear", align_corners=True)) (core/update.py:93-95)."""
+    B, C, H, W = x.shape
+    rc = _ffi.lib().dkt_interp_c8(x.data_ptr(), x.stride(0), dst.data_ptr(), dst.bstride_bytes, B, C, H, W, dst.H, dst.W, ch0,
+                                  dst.scale, _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_interp_c8")
+    return dst
+
+
+def stem7_c8(x, layer, dst, relu=True, ch0=0):
+    """dst[ch0 : ...] = C8S([relu](conv7x7(x))) for the 2- / 1-channel stems (core/update.py:75)."""
+    from . import conv as _conv
+    B, cin, H, W = x.shape
+    w, b = layer.weight, layer.bias
+    key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+    L = _ffi.lib()
+    with _CACHE_LOCK:
+        pk = _conv._stem7_packed(layer, key, L)
+    in_scale = 2.0 ** _conv.in_exp_of(layer)
+    rc = L.dkt_conv2d_stem7_c8(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
+                               None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale / in_scale, in_scale,
+                               dst.data_ptr(), dst.bstride_bytes, ch0, dst.scale, B, cin, int(w.shape[0]), H, W, int(bool(relu)),
+                               _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_conv2d_stem7_c8")
+    return dst

@@ -205,7 +205,7 @@ class CorrBlock1D:
         tensor calls ``materialize()`` and gets exactly ``self(coords)``."""
         return DeferredLookup(self, coords)
 
-    def lookup_conv1x1(self, coords, layer, relu=True, tap=False):
+    def lookup_conv1x1(self, coords, layer, relu=True, tap=False, out_c8=None, out_c8_ch0=0):
         """relu(layer(self(coords))) for a 1x1 ``layer`` with <= 64 outputs, without ever writing the
         lookup.  Returns None when the fused kernel does not cover this configuration (row layout,
         unsupported L / r / layer, autograd involved): run the two steps separately then.
@@ -235,6 +235,17 @@ class CorrBlock1D:
                 hit = cache[str(w.device)] = (key, w.detach().reshape(cout, -1).t().float().contiguous())
         wm = hit[1]
         bias = layer.bias
+        if out_c8 is not None:
+            # straight into the C8S operand of the next convolution (conv_c8.hip); four levels only
+            if self.num_levels != 4 or tap:
+                return None
+            rc = _ffi.lib().dkt_corr1d_lookup_conv1x1_c8(
+                _ffi.ptr_array(self._skew), coords.data_ptr(), coords.stride(0), wm.data_ptr(),
+                None if bias is None else bias.detach().data_ptr(), out_c8.data_ptr(), out_c8.bstride_bytes, out_c8_ch0,
+                out_c8.scale, B, H, W1, self._w2, self.num_levels, self.radius, cout, int(bool(relu)),
+                _ffi.device_of(coords), _ffi.stream_of(coords))
+            _ffi.check(rc, "dkt_corr1d_lookup_conv1x1_c8")
+            return out_c8
         out = torch.empty((B, cout, H, W1), device=coords.device, dtype=torch.float32)
         tp = torch.empty((B, self.num_levels * K, H, W1), device=coords.device, dtype=torch.float32) if tap else None
         rc = _ffi.lib().dkt_corr1d_lookup_conv1x1(

@@ -33,6 +33,11 @@ struct CorrFeatArgs {
     long HW;
     int H, W1, W2, pitch, nseg, Cout, relu;
     float inv_wm1[DKT_MAX_LEVELS];
+    // optional C8S destination (the operand layout of conv_c8.hip; 16-pixel form only)
+    char *out_c8;
+    long out_c8_bs, out_c8_plane;
+    int out_c8_Wp, out_c8_ch0;
+    float act_scale;
 };
 
 __device__ __forceinline__ int cf_clamp_idx(float fl, int W) {
@@ -355,8 +360,42 @@ __global__ __launch_bounds__(256) void corr_feat16_kernel(CorrFeatArgs a) {
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][s], v[s], acc[m], 0, 0, 0);
 
     // ---- epilogue: C/D map of the 16x16 form: col = l & 15 (pixel), row = 4 (l >> 4) + r
-    float *ob = a.out + (size_t)b * a.out_bstride + hrow * a.W1 + w1c;
     const bool full = 16 * MT <= a.Cout && seg0 + 16 <= a.W1;      // wave-uniform: no guards needed
+    if (a.out_c8) {
+        // C8S (fp16 hi | lo, 8 consecutive channels per 16 bytes): quarter-wave g holds channels 4g .. 4g+3 of tile m;
+        // lanes l and l ^ 16 exchange their packed halves, then the even quarter stores the hi 16 bytes of channel
+        // group 2m + (g >> 1), the odd quarter the lo 16 bytes -- one 16-byte store per lane and tile instead of four
+        // 4-byte ones into four channel planes
+        char *pb = a.out_c8 + (size_t)b * a.out_c8_bs + ((size_t)(hrow + 1) * a.out_c8_Wp + (w1c + 1)) * 16;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            unsigned hw[2], lw[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                float y0 = __fadd_rn(acc[m][2 * d], bv[m][2 * d]), y1 = __fadd_rn(acc[m][2 * d + 1], bv[m][2 * d + 1]);
+                if (a.relu) { y0 = dkt_relu(y0); y1 = dkt_relu(y1); }
+                if (16 * m + 4 * g + 2 * d >= a.Cout) y0 = 0.0f;
+                if (16 * m + 4 * g + 2 * d + 1 >= a.Cout) y1 = 0.0f;
+                y0 *= a.act_scale; y1 *= a.act_scale;
+                const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+                union { _Float16 h[2]; unsigned u; } t0, t1;
+                t0.h[0] = h0; t0.h[1] = h1;
+                t1.h[0] = (_Float16)(y0 - (float)h0); t1.h[1] = (_Float16)(y1 - (float)h1);
+                hw[d] = t0.u; lw[d] = t1.u;
+            }
+            // even quarters need the partner's hi words, odd quarters the partner's lo words
+            const bool even = (g & 1) == 0;
+            const unsigned s0 = __shfl_xor(even ? lw[0] : hw[0], 16), s1 = __shfl_xor(even ? lw[1] : hw[1], 16);
+            // what arrived: from an odd partner (we are even) its hi words; from an even partner (we are odd) its lo words
+            const uint4 v = even ? make_uint4(hw[0], hw[1], s0, s1) : make_uint4(s0, s1, lw[0], lw[1]);
+            if (live) {
+                const int grp = ((a.out_c8_ch0 + 16 * m) >> 3) + (g >> 1);
+                *(uint4 *)(pb + (size_t)grp * 2 * a.out_c8_plane + (even ? 0 : a.out_c8_plane)) = v;
+            }
+        }
+        return;
+    }
+    float *ob = a.out + (size_t)b * a.out_bstride + hrow * a.W1 + w1c;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -382,12 +421,13 @@ static int cf16_launch(CorrFeatArgs a, int B, hipStream_t st) {
     return dkt_launch_status();
 }
 
-extern "C" int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *coords_x, long coords_bstride,
-                                         const float *weight, const float *bias, float *out, long out_bstride,
-                                         float *tap, long tap_bstride,
-                                         int B, int H, int W1, int W2, int L, int r, int Cout, int relu,
-                                         int device, void *stream) {
-    if (!skew || !coords_x || !weight || !out) return DKT_E_NULL;
+static int corr_feat_impl(const float *const *skew, const float *coords_x, long coords_bstride,
+                          const float *weight, const float *bias, float *out, long out_bstride,
+                          float *tap, long tap_bstride, void *out_c8, long out_c8_bstride_bytes, int out_c8_ch0, float act_scale,
+                          int B, int H, int W1, int W2, int L, int r, int Cout, int relu,
+                          int device, void *stream) {
+    if (!skew || !coords_x || !weight || (!out && !out_c8)) return DKT_E_NULL;
+    if (out_c8 && (L != 4 || (out_c8_ch0 & 7) || !(act_scale > 0.0f))) return DKT_E_UNSUPPORTED;
     if (B <= 0 || H <= 0 || W1 <= 0 || W2 <= 0 || B > 65535 || Cout <= 0) return DKT_E_SHAPE;
     if (L < 1 || L > DKT_MAX_LEVELS || (W2 >> (L - 1)) == 0) return DKT_E_LEVELS;
     if (r < 0 || r > DKT_MAX_RADIUS) return DKT_E_RADIUS;
@@ -414,8 +454,13 @@ extern "C" int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *
     a.nseg = (W1 + 31) / 32;
     a.Cout = Cout;
     a.relu = relu ? 1 : 0;
+    int Hp = 0, Wp = 0;
+    dkt_act_c8_dims(H, W1, &Hp, &Wp);
+    a.out_c8 = (char *)out_c8; a.out_c8_bs = out_c8_bstride_bytes; a.out_c8_plane = (long)Hp * Wp * 16;
+    a.out_c8_Wp = Wp; a.out_c8_ch0 = out_c8_ch0; a.act_scale = act_scale;
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
+    if (out_c8) return r == 4 ? cf16_launch<4>(a, B, st) : cf16_launch<3>(a, B, st);
     // four levels: the 16-pixel form (one level per quarter-wave); DKT_CORR_FEAT_PX=32 forces the half-wave form
     static const bool px32 = [] { const char *e = getenv("DKT_CORR_FEAT_PX"); return e && atoi(e) == 32; }();
     if (L == 4 && !px32) return r == 4 ? cf16_launch<4>(a, B, st) : cf16_launch<3>(a, B, st);
@@ -427,4 +472,23 @@ extern "C" int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *
     if (L == 4) return cf_launch<4, 3>(a, B, st);
     if (L == 3) return cf_launch<3, 3>(a, B, st);
     return cf_launch<2, 3>(a, B, st);
+}
+
+extern "C" int dkt_corr1d_lookup_conv1x1(const float *const *skew, const float *coords_x, long coords_bstride,
+                                         const float *weight, const float *bias, float *out, long out_bstride,
+                                         float *tap, long tap_bstride,
+                                         int B, int H, int W1, int W2, int L, int r, int Cout, int relu,
+                                         int device, void *stream) {
+    if (!out) return DKT_E_NULL;
+    return corr_feat_impl(skew, coords_x, coords_bstride, weight, bias, out, out_bstride, tap, tap_bstride, nullptr, 0, 0, 1.0f,
+                          B, H, W1, W2, L, r, Cout, relu, device, stream);
+}
+
+extern "C" int dkt_corr1d_lookup_conv1x1_c8(const float *const *skew, const float *coords_x, long coords_bstride,
+                                            const float *weight, const float *bias, void *out_c8, long out_c8_bstride_bytes,
+                                            int out_c8_ch0, float act_scale, int B, int H, int W1, int W2, int L, int r, int Cout,
+                                            int relu, int device, void *stream) {
+    if (!out_c8) return DKT_E_NULL;
+    return corr_feat_impl(skew, coords_x, coords_bstride, weight, bias, nullptr, 0, nullptr, 0, out_c8, out_c8_bstride_bytes,
+                          out_c8_ch0, act_scale, B, H, W1, W2, L, r, Cout, relu, device, stream);
 }

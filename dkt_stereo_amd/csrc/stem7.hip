@@ -28,6 +28,11 @@ struct Stem7Args {
     long y_bs;
     int Cin, Cout, CoutPad, H, W, tiles_w, tiles_xy, n_co;
     int relu;
+    // optional C8S destination (conv_c8.hip's operand layout) instead of / besides the fp32 NCHW one
+    char *y_c8;
+    long y_c8_bs, y_c8_plane;
+    int y_c8_Wp, y_c8_ch0;
+    float act_scale;
 };
 
 // block = 4 waves = 4 output rows x 32 columns x 64 output channels; grid.x = spatial tile * n_co + co block
@@ -94,18 +99,53 @@ __global__ __launch_bounds__(256) void conv2d_stem7_kernel(Stem7Args a) {
     }
     // ---- epilogue: un-scale, bias, ReLU; lane li = column, kg picks the channel sub-block
     const int oh = h0 + wave, ow = w0 + li;
-    if (oh >= a.H || ow >= a.W) return;
-    float *yo = a.y + (long)b * a.y_bs + (long)oh * a.W + ow;
+    const bool inside = oh < a.H && ow < a.W;
+    float *yo = a.y ? a.y + (long)b * a.y_bs + (long)(inside ? oh : 0) * a.W + (inside ? ow : 0) : nullptr;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + m * 32 + 4 * kg + (r & 3) + 8 * (r >> 2);
-            if (co >= a.Cout) continue;
-            float v = acc[m][r] * a.out_scale + (a.bias ? a.bias[co] : 0.0f);
-            if (a.relu) v = dkt_relu(v);
-            yo[(long)co * HW] = v;
+            float t = acc[m][r] * a.out_scale + (a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f);
+            if (a.relu) t = dkt_relu(t);
+            v[r] = co < a.Cout ? t : 0.0f;
+            if (yo && inside && co < a.Cout) yo[(long)co * HW] = v[r];
         }
+        if (a.y_c8) {
+            // C8S: groups of 8 consecutive channels per 16 bytes -- pairs of the lane's 4-channel groups are completed
+            // by exchanging halves with lane ^ 32 (as conv_c8.hip's epilogue)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned ha[2], la[2], hb[2], lb[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const float x0 = v[8 * jp + 2 * d] * a.act_scale, x1 = v[8 * jp + 2 * d + 1] * a.act_scale;
+                    const float y0 = v[8 * jp + 4 + 2 * d] * a.act_scale, y1 = v[8 * jp + 4 + 2 * d + 1] * a.act_scale;
+                    const _Float16 a0 = (_Float16)x0, a1 = (_Float16)x1, b0 = (_Float16)y0, b1 = (_Float16)y1;
+                    union { _Float16 h[2]; unsigned u; } t0, t1, t2, t3;
+                    t0.h[0] = a0; t0.h[1] = a1;
+                    t1.h[0] = (_Float16)(x0 - (float)a0); t1.h[1] = (_Float16)(x1 - (float)a1);
+                    t2.h[0] = b0; t2.h[1] = b1;
+                    t3.h[0] = (_Float16)(y0 - (float)b0); t3.h[1] = (_Float16)(y1 - (float)b1);
+                    ha[d] = t0.u; la[d] = t1.u; hb[d] = t2.u; lb[d] = t3.u;
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    auto r = __builtin_amdgcn_permlane32_swap(ha[d], hb[d], false, false);
+                    ha[d] = r[0]; hb[d] = r[1];
+                    auto q = __builtin_amdgcn_permlane32_swap(la[d], lb[d], false, false);
+                    la[d] = q[0]; lb[d] = q[1];
+                }
+                if (inside) {
+                    const int g = ((a.y_c8_ch0 + co0 + m * 32) >> 3) + 2 * jp + kg;
+                    char *p = a.y_c8 + (long)b * a.y_c8_bs + (long)g * 2 * a.y_c8_plane + ((long)(oh + 1) * a.y_c8_Wp + (ow + 1)) * 16;
+                    *(uint4 *)p = make_uint4(ha[0], ha[1], hb[0], hb[1]);
+                    *(uint4 *)(p + a.y_c8_plane) = make_uint4(la[0], la[1], lb[0], lb[1]);
+                }
+            }
+        }
+    }
 }
 
 // (Cout, Cin, 7, 7) fp32 -> hi/lo fp16 [step = 2*dy + half][coPad][16], k = (dx - 4*half)*4 + ci
@@ -142,12 +182,13 @@ extern "C" int dkt_conv2d_stem7_pack(const float *w, int Cout, int Cin, float sc
     return dkt_launch_status();
 }
 
-extern "C" int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
-                                const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
-                                int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream) {
-    if (!x || !w_hi || !w_lo || !y) return DKT_E_NULL;
+static int stem7_impl(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
+                      const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
+                      void *y_c8, long y_c8_bstride_bytes, int y_c8_ch0, float act_scale,
+                      int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream) {
+    if (!x || !w_hi || !w_lo || (!y && !y_c8)) return DKT_E_NULL;
     if (B <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || H <= 0 || W <= 0 || B > 65535) return DKT_E_SHAPE;
-    if (!(in_scale > 0.0f) || !(out_scale > 0.0f)) return DKT_E_SHAPE;
+    if (!(in_scale > 0.0f) || !(out_scale > 0.0f) || !(act_scale > 0.0f) || (y_c8_ch0 & 7)) return DKT_E_SHAPE;
     Stem7Args a;
     a.x = x; a.x_bs = x_bstride;
     a.whi = (const _Float16 *)w_hi; a.wlo = (const _Float16 *)w_lo;
@@ -159,9 +200,30 @@ extern "C" int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi
     a.tiles_xy = a.tiles_w * ((H + 3) / 4);
     a.n_co = a.CoutPad / 64;
     a.relu = relu ? 1 : 0;
+    int Hp = 0, Wp = 0;
+    dkt_act_c8_dims(H, W, &Hp, &Wp);
+    a.y_c8 = (char *)y_c8; a.y_c8_bs = y_c8_bstride_bytes; a.y_c8_plane = (long)Hp * Wp * 16; a.y_c8_Wp = Wp; a.y_c8_ch0 = y_c8_ch0;
+    a.act_scale = act_scale;
     const long blocks = (long)a.tiles_xy * a.n_co;
     if (blocks > 0x7fffffffL) return DKT_E_SHAPE;
     DKT_ENTER(device);
     hipLaunchKernelGGL(conv2d_stem7_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
     return dkt_launch_status();
+}
+
+extern "C" int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
+                                const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
+                                int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream) {
+    if (!y) return DKT_E_NULL;
+    return stem7_impl(x, x_bstride, w_hi, w_lo, bias, out_scale, in_scale, y, y_bstride, nullptr, 0, 0, 1.0f,
+                      B, Cin, Cout, H, W, relu, device, stream);
+}
+
+extern "C" int dkt_conv2d_stem7_c8(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
+                                   const float *bias, float out_scale, float in_scale, void *y_c8, long y_c8_bstride_bytes,
+                                   int y_c8_ch0, float act_scale, int B, int Cin, int Cout, int H, int W, int relu,
+                                   int device, void *stream) {
+    if (!y_c8) return DKT_E_NULL;
+    return stem7_impl(x, x_bstride, w_hi, w_lo, bias, out_scale, in_scale, nullptr, 0, y_c8, y_c8_bstride_bytes, y_c8_ch0,
+                      act_scale, B, Cin, Cout, H, W, relu, device, stream);
 }

@@ -1,0 +1,119 @@
+"""The RAFT-Stereo refinement loop (meta_arch/raft_stereo/raft_stereo.py:146-167 with the update block of
+core/update.py:97-138) on the round-3 convolution (csrc/conv_c8.hip): every 3x3 layer of the update block reads
+pre-split "C8S" activations that its producers write from their epilogues, hidden states are kept twice (fp32 NCHW for the
+gate arithmetic / resampling, C8S for the convolutions).
+
+Schedule (the rotated one of RAFTStereo._iterate_rotated, on one stream -- kernels on different streams do not
+overlap usefully on this part, tools/concurrency_probe.py):
+    prologue: gru32(0)
+    unit(i) : gru16(i) ; lookup + motion encoder(i) ; gru08(i) paired with gru32(i+1) ; flow head(i)
+Every GRU sees exactly the operands of the reference's sequential order."""
+import os
+
+import torch
+
+from . import _ffi
+from . import conv as _conv
+from . import conv_c8 as c8
+from .update import interp, pool2x, _leading_outputs
+
+#: tile shapes (conv_c8.hip c8_dispatch) per layer class; DKT_C8_CFG="zr08,q08,zr16,q16,head,enc,c2" overrides
+_CFG = dict(zr08=1, q08=2, zr16=3, q16=4, head=2, enc=2, c2=3)
+if os.environ.get("DKT_C8_CFG"):
+    _CFG.update(zip(("zr08", "q08", "zr16", "q16", "head", "enc", "c2"), (int(v) for v in os.environ["DKT_C8_CFG"].split(","))))
+
+
+def eligible(model):
+    a = model.args
+    ub = model.update_block
+    if a.n_gru_layers != 3 or a.slow_fast_gru or _conv.get_backend() != "f16x3":
+        return False
+    if any(getattr(m, "dkt_in_exp", 0) for m in ub.modules()):
+        return False                      # calibrated activation exponents: the round-2 kernels handle those
+    hd = list(a.hidden_dims)
+    return hd == [128, 128, 128] and ub.encoder.conv.weight.shape[0] == 126
+
+
+class C8Loop:
+    """Buffers and the captured unit for one (shape, weights) state of RAFTStereo._iterate_graphed."""
+
+    def __init__(self, model, st):
+        self.model = model
+        ub = model.update_block
+        n0, n1, n2 = st["net"]
+        dev = n0.device
+        B = n0.shape[0]
+        A = lambda t, C=128: c8.ActC8(B, C, t.shape[2], t.shape[3], dev)
+        self.hc8 = [A(n0), A(n1), A(n2)]
+        self.rh = [A(n0), A(n1), A(n2)]
+        self.up1, self.mf = A(n0), A(n0)                  # gru08 operands: interp(net[1]), motion features
+        self.pool0, self.up2 = A(n1), A(n1)               # gru16 operands: pool2x(net[0]), interp(net[2])
+        self.pool1 = A(n2)                                # gru32 operand: pool2x(net[1])
+        self.cor, self.flo = A(n0, 64), A(n0, 64)
+        self.cf = A(n0, 128)
+        self.hidden = torch.empty((B, 256, n0.shape[2], n0.shape[3]), device=dev, dtype=torch.float32)
+        self.graph = None
+
+    # ---- pieces -------------------------------------------------------------------------------------------------
+    def _gru(self, lvl, gru, st, xs, cfg_zr, cfg_q):
+        h = st["net"][lvl]
+        cz, cr, cq = st["inp"][lvl]
+        z = c8.gate_zr([self.hc8[lvl], *xs], gru._merged_zr(), cz, cr, h, rh_c8=self.rh[lvl], cfg=cfg_zr)
+        c8.gate_out([self.rh[lvl], *xs], gru.convq, cq, z, h, h, out_c8=self.hc8[lvl], cfg=cfg_q)
+
+    def _gru_pair(self, st):
+        """gru08 of this iteration and gru32 of the next one in two shared launches."""
+        ub = self.model.update_block
+        ds = []
+        zs = []
+        for lvl, gru, xs in ((0, ub.gru08, [self.mf, self.up1]), (2, ub.gru32, [self.pool1])):
+            h = st["net"][lvl]
+            cz, cr, _ = st["inp"][lvl]
+            z = torch.empty_like(h)
+            zs.append(z)
+            ds.append(c8.desc([self.hc8[lvl], *xs], gru._merged_zr(), out=z, epilogue=1, e0=cz, e1=cr, h=h, out2_c8=self.rh[lvl]))
+        c8.launch_pair(ds[0], ds[1], zs[0], _CFG["zr08"])
+        ds = []
+        for (lvl, gru, xs), z in zip(((0, ub.gru08, [self.mf, self.up1]), (2, ub.gru32, [self.pool1])), zs):
+            h = st["net"][lvl]
+            cq = st["inp"][lvl][2]
+            ds.append(c8.desc([self.rh[lvl], *xs], gru.convq, out=h, out_c8=self.hc8[lvl], epilogue=2, e0=cq, e1=z, h=h))
+        c8.launch_pair(ds[0], ds[1], zs[0], _CFG["q08"])
+
+    def _motion(self, st):
+        enc = self.model.update_block.encoder
+        if st["corr"].lookup_conv1x1(st["coords1"], enc.convc1, out_c8=self.cor) is None:
+            c8.pack(st["corr"].lookup_conv1x1(st["coords1"], enc.convc1), self.cor)
+        c8.stem7_c8(st["flow"], enc.convf1, self.flo)
+        d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
+        d1 = c8.desc([self.flo], enc.convf2, relu=True, out_c8=self.cf, out_c8_ch0=64)
+        c8.launch_pair(d0, d1, st["flow"], _CFG["c2"])
+        c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["flow"], cfg=_CFG["enc"])
+
+    def _head(self, st):
+        fh = self.model.update_block.flow_head
+        c8.conv2d_c8([self.hc8[0]], fh.conv1, relu=True, out=self.hidden, cfg=_CFG["head"])
+        _conv.conv2d_accumulate(self.hidden, _leading_outputs(fh.conv2, 1), st["coords1"][:, :1],
+                                diff=(st["coords0"][:, :1], st["flow"][:, :1]))
+
+    def _mid(self, st):
+        n0, n1, n2 = st["net"]
+        c8.pool2x_c8(n0, self.pool0)
+        c8.interp_c8(n2, self.up2)
+        self._gru(1, self.model.update_block.gru16, st, [self.pool0, self.up2], _CFG["zr16"], _CFG["q16"])
+        c8.interp_c8(n1, self.up1)
+        c8.pool2x_c8(n1, self.pool1)
+
+    def unit(self, st):
+        self._mid(st)
+        self._motion(st)
+        self._gru_pair(st)
+        self._head(st)
+
+    def prologue(self, st):
+        """Per pair: hidden states into their C8S twins, then gru32 of iteration 0."""
+        n0, n1, n2 = st["net"]
+        for lvl, n in enumerate(st["net"]):
+            c8.pack(n, self.hc8[lvl])
+        c8.pool2x_c8(n1, self.pool1)
+        self._gru(2, self.model.update_block.gru32, st, [self.pool1], 4, 4)

@@ -420,6 +420,36 @@ class RAFTStereo(nn.Module):
         with harness(inplace_state=True, side_stream=False):
             return self._stage_head(nets, st["coords1"], True, st["coords0"], st["flow"])
 
+    #: round 3: the loop on the C8S convolution (loop_c8.py); DKT_C8=0 keeps the round-2 kernels and schedule
+    use_c8 = os.environ.get("DKT_C8", "1") != "0"
+
+    def _iterate_c8(self, st, iters):
+        """loop_c8.C8Loop: prologue, `iters` units (the first eagerly, one captured, the rest replayed), mask head."""
+        from . import loop_c8
+        lp = st.get("c8")
+        if lp is None:
+            lp = st["c8"] = loop_c8.C8Loop(self, st)
+        if "flow" not in st:
+            b, _, h, w = st["coords1"].shape
+            st["feat"], st["flow"] = self.update_block.encoder.new_feature_buffer(b, h, w, st["coords1"].device)
+        torch.sub(st["coords1"], st["coords0"], out=st["flow"])
+        ub = self.update_block
+        with harness(inplace_state=True, side_stream=False):
+            lp.prologue(st)
+            done = 0
+            if lp.graph is None:
+                lp.unit(st)                  # eager once: packs weights, sizes the allocator
+                done = 1
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with capture_graph(g):
+                    lp.unit(st)
+                lp.graph = g
+                done = 2
+            for _ in range(iters - done):
+                replay_graph(lp.graph)
+            return .25 * conv2d(conv2d(st["net"][0], ub.mask[0], relu=True), ub.mask[2])
+
     def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init):
         """Same arithmetic as the eager loop; iterations 2..iters-1 are replays of one
         captured HIP graph (~60 launches per iteration leave the CPU out of the loop)."""
@@ -429,7 +459,7 @@ class RAFTStereo(nn.Module):
         # weights and the biases, all of which are re-created when a parameter is replaced or written
         # (load_state_dict, .to(), optimiser steps) or the conv backend changes: those are part of the key.
         key = (fmap1.device, tuple(fmap1.shape), tuple(fmap2.shape), args.corr_implementation,
-               self._weights_fingerprint(), self.rotate, self.pair_grus, self.pipeline_grus, self.fuse_lookup)
+               self._weights_fingerprint(), self.rotate, self.pair_grus, self.pipeline_grus, self.fuse_lookup, self.use_c8)
         st = self._graph_state
         if st is None or st["key"] != key:
             st = dict(key=key, graph=None)
@@ -450,6 +480,12 @@ class RAFTStereo(nn.Module):
                     dst.copy_(src)
         if flow_init is not None:
             st["coords1"].add_(flow_init)
+        if self.use_c8 and iters >= 3:
+            from . import loop_c8
+            if loop_c8.eligible(self):
+                up_mask = self._iterate_c8(st, iters)
+                flow = st["coords1"] - st["coords0"]
+                return flow, self.upsample_flow(flow, up_mask)[:, :1]
         if self._can_pipeline() and self.rotate and self.pair_grus:
             up_mask = self._iterate_rotated(st, iters)
             flow = st["coords1"] - st["coords0"]

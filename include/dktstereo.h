@@ -399,6 +399,73 @@ int dkt_instance_norm_finalize(const void *workspace, int planes, long HW, float
 
 int dkt_add_relu(const float *a, const float *b, float *y, long n, int device, void *stream);
 
+/* ---- round 3: the 3x3 convolution on pre-split activations ("C8S" layout, conv_c8.hip) -------------------------
+ * Same operator and arithmetic as dkt_conv2d_f16s(passes = 3) -- core/update.py:19-21,27-31 (ConvGRU), :72-76,84
+ * (motion encoder), :9 (FlowHead.conv1) -- but the activation operands arrive as fp16 (hi, lo) pairs written by the
+ * producing kernel, so that both operands reach LDS by DMA.
+ *
+ * C8S tensor of C channels at H x W:  [B][G = 2*ceil(C/16)][2: hi, lo][Hp][Wp][8] fp16 with
+ * Hp = roundup(H, 8) + 2, Wp = roundup(W, 32) + 2 (dkt_act_c8_dims); pixel (y, x) lives at (y+1, x+1); the border and the
+ * padding channels MUST be zero (allocate zeroed; producers write the interior only).  value = (hi + lo) / scale. */
+int dkt_act_c8_dims(int H, int W, int *Hp, int *Wp);
+/* fp32 NCHW (B,C,H,W) -> channels [ch0, ch0+C) of a C8S tensor (ch0 a multiple of 8), and back (tests, glue). */
+int dkt_act_c8_pack(const float *x, long x_bstride, void *dst, long dst_bstride_bytes, int B, int C, int H, int W,
+                    int ch0, float scale, int device, void *stream);
+int dkt_act_c8_unpack(const void *src, long src_bstride_bytes, float *y, long y_bstride, int B, int C, int H, int W,
+                      int ch0, float scale, int device, void *stream);
+/* weights (Cout, sum(src_channels), 3, 3) fp32 -> the kernel's step images [chunk][tap][co/64][hi|lo][k/8][64][8] fp16
+ * (every source padded to a multiple of 16 channels, Cout to 64); `scale` a power of two as for dkt_conv2d_pack_weights. */
+long dkt_conv_c8_packed_bytes(const int *src_channels, int nsrc, int Cout);
+int dkt_conv_c8_pack_weights(const float *w, const int *src_channels, int nsrc, int Cout, float scale,
+                             void *packed, int device, void *stream);
+typedef struct dkt_conv_c8_desc {
+    const void *src[DKT_CONV_MAX_SRC];      /* C8S operands = the reference's torch.cat list, all H x W */
+    long src_bstride[DKT_CONV_MAX_SRC];     /* bytes per batch item */
+    int src_channels[DKT_CONV_MAX_SRC];
+    int nsrc;
+    const void *w;                          /* dkt_conv_c8_pack_weights image */
+    const float *bias;
+    float out_scale;                        /* 1 / (weight scale * activation scale of the sources) */
+    float act_scale;                        /* power of two applied to C8S OUTPUTS before the split */
+    int B, H, W, Cout, relu;
+    int epilogue;                           /* 0 plain, 1 ConvGRU z|r gates, 2 ConvGRU state update (as dkt_conv_desc) */
+    float *out; long out_bstride;           /* fp32 NCHW destination (optional when out_c8 is given; epilogue 1: z) */
+    void *out_c8; long out_c8_bstride;      /* C8S destination (optional), bytes per batch item; epilogue 2: h' */
+    int out_c8_ch0;                         /* first channel written (multiple of 8) */
+    const float *e0; long e0_bstride;       /* cz | cq */
+    const float *e1; long e1_bstride;       /* cr | z  */
+    const float *h;  long h_bstride;
+    float *out2; long out2_bstride;         /* epilogue 1: r*h as fp32 NCHW (optional) */
+    void *out2_c8; long out2_c8_bstride;    /* epilogue 1: r*h as C8S (optional; same H, W) */
+    int out2_c8_ch0;
+    const float *tail; long tail_bstride;   /* epilogue 0 + out_c8: channels Cout .. Cout+tail_channels-1 of the C8S output are */
+    int tail_channels;                      /* copied from this fp32 NCHW tensor: torch.cat([out, flow]) of core/update.py:85 */
+    int f32_c4;                             /* 1: out, out2, e0, e1, h are "C4" tensors [B][ceil(C/4)][H][W][4] (one 16-byte access per
+                                             * lane and channel quad in the epilogue) instead of NCHW; bstrides stay in floats */
+} dkt_conv_c8_desc;
+/* cfg: 0 = tile shape by layer / image size, 1..5 force one (conv_c8.hip c8_dispatch). */
+int dkt_conv2d_c8(const dkt_conv_c8_desc *d, int cfg, int device, void *stream);
+/* two independent convolutions in one launch (the coarsest GRU rides with the finest); cfg != 0 */
+int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_desc *d1, int cfg, int device, void *stream);
+
+/* Producers of C8S operands besides the convolution epilogues (same arithmetic as their fp32 twins):
+ *   dkt_pool2x_c8 / dkt_interp_c8 : pool2x / interp of core/update.py:87-95, fp32 NCHW in (B,C,H,W);
+ *   dkt_conv2d_stem7_c8           : the 7x7 stem (convf1, core/update.py:75);
+ *   dkt_corr1d_lookup_conv1x1_c8  : lookup fused with convc1 (core/corr.py:127-146 + core/update.py:76), L = 4 only.
+ * ch0 (multiple of 8) = first channel written, act_scale the C8S tensor's power-of-two scale. */
+int dkt_pool2x_c8(const float *x, long x_bstride, void *dst, long dst_bstride_bytes, int B, int C, int H, int W,
+                  int ch0, float scale, int device, void *stream);
+int dkt_interp_c8(const float *x, long x_bstride, void *dst, long dst_bstride_bytes, int B, int C, int H, int W,
+                  int Ho, int Wo, int ch0, float scale, int device, void *stream);
+int dkt_conv2d_stem7_c8(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
+                        const float *bias, float out_scale, float in_scale, void *y_c8, long y_c8_bstride_bytes,
+                        int y_c8_ch0, float act_scale, int B, int Cin, int Cout, int H, int W, int relu,
+                        int device, void *stream);
+int dkt_corr1d_lookup_conv1x1_c8(const float *const *skew, const float *coords_x, long coords_bstride,
+                                 const float *weight, const float *bias, void *out_c8, long out_c8_bstride_bytes,
+                                 int out_c8_ch0, float act_scale, int B, int H, int W1, int W2, int L, int r, int Cout,
+                                 int relu, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
