@@ -44,7 +44,8 @@ class ConvC8Desc(ctypes.Structure):
                 ("h", ctypes.c_void_p), ("h_bstride", ctypes.c_long), ("out2", ctypes.c_void_p), ("out2_bstride", ctypes.c_long),
                 ("out2_c8", ctypes.c_void_p), ("out2_c8_bstride", ctypes.c_long), ("out2_c8_ch0", ctypes.c_int),
                 ("tail", ctypes.c_void_p), ("tail_bstride", ctypes.c_long), ("tail_channels", ctypes.c_int),
-                ("f32_c4", ctypes.c_int)]
+                ("head_w", ctypes.c_void_p), ("head_out", ctypes.c_void_p), ("head_out_bstride", ctypes.c_long),
+                ("head_outputs", ctypes.c_int), ("f32_c4", ctypes.c_int)]
 
 
 # name -> argtypes, mirrors include/dktstereo.h one to one
@@ -53,6 +54,8 @@ SIGNATURES = {
     "dkt_interp_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_conv2d_stem7_c8": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_corr1d_lookup_conv1x1_c8": [_pp, _vp, _l, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dkt_conv2d_c8_head_blocks": [_i, _i],
+    "dkt_head_finish": [_vp, _l, _i, _vp, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp],
     "dkt_act_c8_dims": [_i, _i, _ip, _ip],
     "dkt_act_c8_pack": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_act_c8_unpack": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],

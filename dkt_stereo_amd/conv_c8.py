@@ -90,7 +90,7 @@ def packed_weights(layer, src_channels):
         wmax = float(w.detach().abs().max())
         e = 12 - math.floor(math.log2(wmax)) if wmax > 0 else 0       # max|w| in [2^12, 2^13): w_lo stays normal
         p = _PackedC8()
-        p.img = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+        p.img = torch.zeros(nbytes // 2, device=w.device, dtype=torch.float16)
         wc = w.detach().float().contiguous()
         rc = L.dkt_conv_c8_pack_weights(wc.data_ptr(), ch, n, cout, 2.0 ** e, p.img.data_ptr(), _ffi.device_of(w), _ffi.stream_of(w))
         _ffi.check(rc, "dkt_conv_c8_pack_weights")
@@ -116,7 +116,7 @@ def from_c4(x, C=None):
 
 
 def desc(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, epilogue=0, e0=None, e1=None, h=None,
-         out2=None, out2_c8=None, out2_c8_ch0=0, tail=None, f32_c4=False):
+         out2=None, out2_c8=None, out2_c8_ch0=0, tail=None, f32_c4=False, head_w=None, head_out=None):
     """dkt_conv_c8_desc; keeps its tensors alive through the returned object."""
     srcs = list(srcs)
     s0 = srcs[0]
@@ -153,7 +153,9 @@ def desc(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, epilogue=
     if tail is not None:
         d.tail_channels = int(tail.shape[1])
     d.f32_c4 = int(bool(f32_c4))
-    d._keep = (srcs, pk, out, out_c8, e0, e1, h, out2, out2_c8, tail)
+    if head_w is not None:
+        d.head_w, d.head_out, d.head_out_bstride, d.head_outputs = head_w.data_ptr(), head_out.data_ptr(), head_out.stride(0), int(head_w.shape[0])
+    d._keep = (srcs, pk, out, out_c8, e0, e1, h, out2, out2_c8, tail, head_w, head_out)
     return d
 
 
@@ -231,3 +233,41 @@ def stem7_c8(x, layer, dst, relu=True, ch0=0):
                                _ffi.device_of(x), _ffi.stream_of(x))
     _ffi.check(rc, "dkt_conv2d_stem7_c8")
     return dst
+
+
+def _head_weights(layer2):
+    """(n_out, Cout, 3, 3) weights of the head's second layer as [n_out][Cout][12] fp32 (cached per device / version)."""
+    w = layer2.weight
+    key = (w.data_ptr(), w._version)
+    with _CACHE_LOCK:
+        cache = layer2.__dict__.setdefault("_dkt_head_w", {})
+        hit = cache.get(str(w.device))
+        if hit is None or hit[0] != key:
+            t = torch.zeros((w.shape[0], w.shape[1], 12), device=w.device, dtype=torch.float32)
+            t[:, :, :9] = w.detach().float().reshape(w.shape[0], w.shape[1], 9)
+            hit = cache[str(w.device)] = (key, t)
+        return hit[1]
+
+
+def head(srcs, layer1, layer2, target, diff=None, cfg=2):
+    """target += layer2(relu(layer1(cat(srcs)))) for the flow / disparity head (core/update.py:6-14; raft_stereo.py:165-168),
+    `layer2` a 3x3 layer with 1 or 2 outputs: the hidden tensor is never written -- layer1's epilogue reduces it against
+    layer2's weights tap by tap (epilogue 3), dkt_head_finish adds the shifted planes.  diff = (ref, dst): dst = target - ref."""
+    s0 = srcs[0]
+    hw = _head_weights(layer2)
+    nout = int(hw.shape[0])
+    L = _ffi.lib()
+    n_co = L.dkt_conv2d_c8_head_blocks(int(layer1.weight.shape[0]), cfg)
+    if n_co <= 0:
+        raise _ffi.DktError("conv_c8.head: tile shape %d cannot run the head epilogue" % cfg)
+    planes = torch.empty((s0.B, nout * n_co * 9, s0.H, s0.W), device=s0.device, dtype=torch.float32)
+    d = desc(srcs, layer1, relu=True, epilogue=3, head_w=hw, head_out=planes)
+    launch(d, planes, cfg)
+    b2 = layer2.bias
+    ref, dst = diff if diff is not None else (None, None)
+    rc = L.dkt_head_finish(planes.data_ptr(), planes.stride(0), n_co, None if b2 is None else b2.detach().data_ptr(),
+                           target.data_ptr(), target.stride(0), None if ref is None else ref.data_ptr(),
+                           0 if ref is None else ref.stride(0), None if dst is None else dst.data_ptr(),
+                           0 if dst is None else dst.stride(0), s0.B, nout, s0.H, s0.W, _ffi.device_of(planes), _ffi.stream_of(planes))
+    _ffi.check(rc, "dkt_head_finish")
+    return target

@@ -54,6 +54,12 @@ struct C8Args {
     float *out2; long out2_bs;         // epi 1: r*h as fp32 NCHW (or null)
     char *out2_c8; long out2_c8_bs;    // epi 1: r*h as C8S (same Hp/Wp/plane as out_c8; channel offset out2_c8_ch0)
     int out2_c8_ch0;
+    // epi 3 (flow / disparity head, core/update.py:9-13 with 1 or 2 outputs): the layer's ReLU output is never written;
+    // its epilogue reduces it over the block's channels against the NEXT layer's 3x3 weights, one plane per (output, tap):
+    // head_out[b][(o * n_co + co block) * 9 + tap][H][W] = sum_co head_w[o][co][tap] * relu(conv)[co]; dkt_head_finish sums
+    // the shifted planes.
+    const float *head_w;               // [n_out][Cout][12] (9 taps + 3 pad)
+    float *head_out; long head_out_bs; int head_nout;
     int f32_c4;                        // the fp32 tensors above (out, out2, e_c0, e_c1, e_h) are [B][C/4][H][W][4] instead of NCHW
     const float *tail; long tail_bs; int tail_ch;   // epi 0: channels Cout .. Cout+tail_ch-1 of the C8S output are copied from here
 };
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
     // group instead of four strided 4-byte ones (a.f32_c4); NCHW remains for tensors other kernels read.
     // C8S outputs need 8 consecutive channels per 16 bytes: a pair of groups (j, j+1) is completed by exchanging
     // halves with lane ^ 32 (v_permlane32_swap), after which the lane stores group 2*jp + kg of its block.
-    auto store_c8_pair = [&](char *dst_b, int ch_block, int jp, int oh, int ow, bool inside, const float (&va)[4], const float (&vb)[4]) {
+    auto store_c8_pair = [&](char *dst_b, int ch_block, int g_end, int jp, int oh, int ow, bool inside, const float (&va)[4], const float (&vb)[4]) {
         unsigned ha[2], la[2], hb[2], lb[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -256,8 +262,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
             auto q = __builtin_amdgcn_permlane32_swap(la[d], lb[d], false, false);
             la[d] = q[0]; lb[d] = q[1];
         }
-        if (inside) {
-            const int g = (ch_block >> 3) + 2 * jp + kg;
+        const int g = (ch_block >> 3) + 2 * jp + kg;
+        if (inside && g < g_end) {            // (groups past the destination's padded channel count do not exist)
             char *p = dst_b + (long)g * 2 * a.out_c8_plane + ((long)(oh + 1) * a.out_c8_Wp + (ow + 1)) * 16;
             *(uint4 *)p = make_uint4(ha[0], ha[1], hb[0], hb[1]);
             *(uint4 *)(p + a.out_c8_plane) = make_uint4(la[0], la[1], lb[0], lb[1]);
@@ -284,7 +290,81 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                 if (i < nvalid) p[(long)i * iHW] = v[i];
         }
     };
+    char *const lds_head = lds + 2 * ACT_BYTES + C8_RING * WSLOT;      // epi 3 only: [wave][NF][9][32] floats
+    auto epilogue_head = [&]() {
+        const int co_w = co_blk + wm * 64;
+        const bool idle = co_w >= a.n_co64 * 64;
+        const int iHW = (int)HW;
+        float *red = (float *)lds_head;
+        int kgo = kg;                          // the lane's channel half, opaque from here on: nothing derived from it
+        asm volatile("" : "+v"(kgo));          // can be pre-computed at kernel entry and kept live (spilled) through the main loop
+        // ONE output (stereo: the x component / the disparity), two tile rows at a time: the accumulators, the next tile's
+        // prefetched fragments and 18 partial sums fit the register file (all NF rows at once, or a loop over outputs that
+        // keeps every accumulator live, spilled 250-400 registers)
+        constexpr int NH = NF > 1 ? 2 : 1;
+#pragma unroll
+        for (int n0 = 0; n0 < NF; n0 += NH) {
+            float P[NH][9];
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) P[n][t] = 0.0f;
+            if (!idle) {
+#pragma unroll
+                for (int m = 0; m < MF; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // channel co = cu + 4 kg: wave-uniform base pointers + one lane offset (Cout is a multiple of 64 here)
+                        const int cu = __builtin_amdgcn_readfirstlane(co_w) + m * 32 + (r & 3) + 8 * (r >> 2);
+                        const float *wp = a.head_w + (long)cu * 12 + kgo * 48;
+                        const float4 w0 = *(const float4 *)wp, w1 = *(const float4 *)(wp + 4);
+                        const float w8 = wp[8];
+                        const float wt[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w8};
+                        const float bias = a.bias[cu + 4 * kgo];                 // (bias is mandatory here: a branch per channel wrecks the allocation)
+#pragma unroll
+                        for (int n = 0; n < NH; ++n) {
+                            const float v = dkt_relu(acc[m][n0 + n][r] * a.out_scale + bias);
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) P[n][t] = __fmaf_rn(wt[t], v, P[n][t]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);       // one channel at a time: no hoisting of all the weight loads
+                    }
+            }
+            // the two half-waves hold different channels of the same pixels
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) P[n][t] = __fadd_rn(P[n][t], __shfl_xor(P[n][t], 32));
+            if (kg == 0) {
+#pragma unroll
+                for (int n = 0; n < NH; ++n)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) red[((wave * NF + n0 + n) * 9 + t) * 32 + li] = P[n][t];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // wave (wm = 0, wn) sums the WM channel quarters of its rows in wave order and writes the planes
+        if (wm == 0) {
+            for (int item = lane; item < NF * 9 * 32; item += 64) {
+                const int px = item & 31, t = (item >> 5) % 9, n = item / (9 * 32);
+                float sum = red[(((0 + WM * wn) * NF + n) * 9 + t) * 32 + px];
+#pragma unroll
+                for (int q = 1; q < WM; ++q) sum = __fadd_rn(sum, red[(((q + WM * wn) * NF + n) * 9 + t) * 32 + px]);
+                const int oh = h0 + wn * NF + n, ow = w0 + px;
+                if (oh < a.H && ow < a.W)
+                    a.head_out[(long)b * a.head_out_bs + ((long)(co_blk / (64 * WM)) * 9 + t) * iHW + (long)oh * a.W + ow] = sum;
+            }
+        }
+        __builtin_amdgcn_s_barrier();                            // `red` is free again before the next tile's epilogue
+    };
     auto epilogue = [&]() {
+        if constexpr (NW == 8 && NF <= 2) {      // (only the 128 co x 8 rows shape carries the head epilogue: in the NF = 4
+            if (a.epi == 3) {                    //  shapes its code costs hundreds of spilled registers)
+                epilogue_head();
+                return;
+            }
+        }
         const int co_w = co_blk + wm * 64;
         if (co_w >= a.n_co64 * 64) return;                   // idle wave
         const int iHW = (int)HW;
@@ -299,6 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         char *pc8 = rpart ? (a.out2_c8 ? a.out2_c8 + (long)b * a.out2_c8_bs : nullptr) : (a.out_c8 ? a.out_c8 + (long)b * a.out_c8_bs : nullptr);
         const int c8_ch0 = rpart ? a.out2_c8_ch0 : a.out_c8_ch0;
         const int cout_eff = a.epi == 1 ? Ch : a.Cout;      // channels of the destination tensors
+        const int c8_gend = 2 * ((c8_ch0 + cout_eff + (a.epi == 0 ? a.tail_ch : 0) + 15) / 16);   // 8-channel groups the C8S destination holds
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
             float bv[16];                                      // this lane's 16 biases of block m
@@ -352,7 +433,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                         if (po && inside && cl < cout_eff)
                             f32_store4(const_cast<float *>(f32_ptr(po, cl, px, iHW)), iHW, v[jj], cout_eff - cl);
                     }
-                    if (pc8) store_c8_pair(pc8, c8_ch0 + cw + m * 32, jp, oh, ow, inside, v[0], v[1]);
+                    if (pc8) store_c8_pair(pc8, c8_ch0 + cw + m * 32, c8_gend, jp, oh, ow, inside, v[0], v[1]);
                 }
             }
         }
@@ -608,7 +689,9 @@ static int c8_chunks(const int *src_ch, int nsrc) {
 
 extern "C" long dkt_conv_c8_packed_bytes(const int *src_channels, int nsrc, int Cout) {
     if (!src_channels || nsrc < 1 || nsrc > C8_MAX_SRC || Cout <= 0) return DKT_E_SHAPE;
-    return (long)c8_chunks(src_channels, nsrc) * 9 * ((Cout + 63) / 64) * 4096;
+    // + 12 KB of slack: a block always copies its tile shape's full 4 x 64 channel step image, also where the layer has fewer
+    // channel blocks (the surplus waves idle on whatever follows)
+    return (long)c8_chunks(src_channels, nsrc) * 9 * ((Cout + 63) / 64) * 4096 + 3 * 4096;
 }
 
 extern "C" int dkt_conv_c8_pack_weights(const float *w, const int *src_channels, int nsrc, int Cout, float scale,
@@ -636,13 +719,19 @@ static int c8_launch(C8Args a, int B, hipStream_t st, const C8Args *second, int 
     constexpr int NW = WM * WN, TR = WN * NF;
     constexpr int NU = (TR + 2) * C8_PC * 4;
     constexpr int NPR = (NU + 63) / 64, NIA = (NPR + NW - 1) / NW;
-    const size_t lds = (size_t)2 * (NIA * NW > NPR ? NPR + 1 : NPR) * 1024 + (size_t)RING * WM * 4096;
+    size_t lds = (size_t)2 * (NIA * NW > NPR ? NPR + 1 : NPR) * 1024 + (size_t)RING * WM * 4096;
+    const bool head = a.epi == 3 || (second && second->epi == 3);
+    if (head) {
+        if (NW != 8 || NF > 2) return DKT_E_UNSUPPORTED;      // one block per CU: the extra LDS costs no residency
+        lds += (size_t)NW * NF * 9 * 32 * 4;
+    }
     auto kern = conv_c8_kernel<WM, WN, NF, RING>;
     static int slots[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!slots[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(lds + (NW == 8 && NF <= 2 && !head ? (size_t)NW * NF * 9 * 32 * 4 : 0)));
         if (e != hipSuccess) return (int)e;
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -686,9 +775,9 @@ static int c8_launch(C8Args a, int B, hipStream_t st, const C8Args *second, int 
 static int c8_fill(C8Args &a, const dkt_conv_c8_desc *d) {
     if (!d) return DKT_E_NULL;
     if (d->nsrc < 1 || d->nsrc > C8_MAX_SRC || d->B <= 0 || d->B > 65535 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return DKT_E_SHAPE;
-    if (!d->w || (!d->out && !d->out_c8 && d->epilogue != 1)) return DKT_E_NULL;
+    if (!d->w || (!d->out && !d->out_c8 && d->epilogue != 1 && d->epilogue != 3)) return DKT_E_NULL;
     if (!(d->out_scale > 0.0f) || !(d->act_scale > 0.0f)) return DKT_E_SHAPE;
-    if (d->epilogue < 0 || d->epilogue > 2) return DKT_E_UNSUPPORTED;
+    if (d->epilogue < 0 || d->epilogue > 3) return DKT_E_UNSUPPORTED;
     int Hp, Wp;
     dkt_act_c8_dims(d->H, d->W, &Hp, &Wp);
     a.nchunks = 0;
@@ -718,6 +807,9 @@ static int c8_fill(C8Args &a, const dkt_conv_c8_desc *d) {
     a.out2 = d->out2; a.out2_bs = d->out2_bstride;
     a.out2_c8 = (char *)d->out2_c8; a.out2_c8_bs = d->out2_c8_bstride; a.out2_c8_ch0 = d->out2_c8_ch0;
     a.f32_c4 = d->f32_c4 ? 1 : 0;
+    a.head_w = d->head_w; a.head_out = d->head_out; a.head_out_bs = d->head_out_bstride; a.head_nout = d->head_outputs;
+    if (a.epi == 3 && (!a.head_w || !a.head_out || !a.bias)) return DKT_E_NULL;
+    if (a.epi == 3 && (a.head_nout != 1 || a.Cout % 64 != 0)) return DKT_E_UNSUPPORTED;       // one output (stereo heads); the 2-output flow head keeps the hidden tensor
     a.tail = d->tail; a.tail_bs = d->tail_bstride; a.tail_ch = d->tail ? d->tail_channels : 0;
     if ((a.out_c8_ch0 & 7) || (a.out2_c8_ch0 & 7)) return DKT_E_SHAPE;
     if (a.epi == 1) {
@@ -769,4 +861,55 @@ extern "C" int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_
     if (cfg == 0) return DKT_E_UNSUPPORTED;          // both problems run one instantiation: the caller names it
     DKT_ENTER(device);
     return c8_dispatch(a, d0->B, cfg, (hipStream_t)stream, &b, d1->B);
+}
+
+// ---- second layer of the flow / disparity head from the planes of epilogue 3 (core/update.py:10-13, 3x3, padding 1):
+//   y[o] = bias[o] + sum over (co block, tap) of plane[(o * n_co + block) * 9 + tap] shifted by the tap;
+//   target[o] += y[o]  (raft_stereo.py:165-168: coords1 = coords1 + delta_flow);  diff_out[o] = target[o] - diff_ref[o]
+__global__ __launch_bounds__(256) void head_finish_kernel(const float *planes, long planes_bs, int n_co, const float *bias,
+                                                          float *target, long target_bs, const float *diff_ref, long diff_ref_bs,
+                                                          float *diff_out, long diff_out_bs, int nout, int H, int W) {
+    const long HW = (long)H * W;
+    const int b = blockIdx.y;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        const int oh = (int)(i / W), ow = (int)(i - (long)oh * W);
+        for (int o = 0; o < nout; ++o) {
+            float s = 0.0f;
+            for (int cb = 0; cb < n_co; ++cb) {
+                const float *p = planes + (long)b * planes_bs + (long)(o * n_co + cb) * 9 * HW;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+                    const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                    const float v = p[(long)t * HW + (in ? (long)ih * W + iw : 0)];
+                    s = __fadd_rn(s, in ? v : 0.0f);
+                }
+            }
+            s = __fadd_rn(s, bias ? bias[o] : 0.0f);
+            float *tp = target + (long)b * target_bs + (long)o * HW + i;
+            const float nv = __fadd_rn(*tp, s);
+            *tp = nv;
+            if (diff_out) diff_out[(long)b * diff_out_bs + (long)o * HW + i] = __fsub_rn(nv, diff_ref[(long)b * diff_ref_bs + (long)o * HW + i]);
+        }
+    }
+}
+
+extern "C" int dkt_head_finish(const float *planes, long planes_bstride, int n_co, const float *bias, float *target,
+                               long target_bstride, const float *diff_ref, long diff_ref_bstride, float *diff_out,
+                               long diff_out_bstride, int B, int nout, int H, int W, int device, void *stream) {
+    if (!planes || !target || (diff_out && !diff_ref)) return DKT_E_NULL;
+    if (B <= 0 || B > 65535 || nout < 1 || nout > 2 || n_co < 1 || H <= 0 || W <= 0) return DKT_E_SHAPE;
+    DKT_ENTER(device);
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(head_finish_kernel, dim3((unsigned)((HW + 255) / 256 > 2048 ? 2048 : (HW + 255) / 256), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, planes, planes_bstride, n_co, bias, target, target_bstride, diff_ref, diff_ref_bstride,
+                       diff_out, diff_out_bstride, nout, H, W);
+    return dkt_launch_status();
+}
+
+// number of output-channel blocks (= planes per output and tap) a head launch with tile shape `cfg` produces
+extern "C" int dkt_conv2d_c8_head_blocks(int Cout, int cfg) {
+    const int n64 = (Cout + 63) / 64;
+    if (cfg == 2) return (n64 + 1) / 2;
+    return DKT_E_UNSUPPORTED;
 }

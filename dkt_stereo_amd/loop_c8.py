@@ -18,13 +18,22 @@ from . import conv_c8 as c8
 from .update import interp, pool2x, _leading_outputs
 
 #: tile shapes (conv_c8.hip c8_dispatch) per layer class; DKT_C8_CFG="zr08,q08,zr16,q16,head,enc,c2" overrides
-_CFG = dict(zr08=1, q08=2, zr16=3, q16=4, head=2, enc=2, c2=3)
+_CFG = dict(zr08=1, q08=2, zr16=4, q16=4, head=2, enc=3, c2=3)
+#: flow head with the hidden tensor reduced in conv1's epilogue (DKT_C8_FUSE_HEAD=0: hidden tensor + few-output kernel)
+FUSE_HEAD = os.environ.get("DKT_C8_FUSE_HEAD", "1") != "0"
 if os.environ.get("DKT_C8_CFG"):
     _CFG.update(zip(("zr08", "q08", "zr16", "q16", "head", "enc", "c2"), (int(v) for v in os.environ["DKT_C8_CFG"].split(","))))
 
 
-def eligible(model):
+#: quarter-resolution pixels (per pair) from which the loop takes this path: the C8S kernel's tiles are 8 rows x 32 columns
+#: x 64-256 channels, smaller images leave most CUs without one (256 x 512: 7.4 ms against 5.4 on the round-2 kernels)
+MIN_PIXELS = int(os.environ.get("DKT_C8_MIN_PIXELS", "24000"))
+
+
+def eligible(model, shape=None):
     a = model.args
+    if shape is not None and shape[2] * shape[3] < MIN_PIXELS:
+        return False
     ub = model.update_block
     if a.n_gru_layers != 3 or a.slow_fast_gru or _conv.get_backend() != "f16x3":
         return False
@@ -92,6 +101,11 @@ class C8Loop:
 
     def _head(self, st):
         fh = self.model.update_block.flow_head
+        if FUSE_HEAD:
+            # conv2 (x output only: raft_stereo.py:165) from per-tap projections made in conv1's epilogue
+            c8.head([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), st["coords1"][:, :1],
+                    diff=(st["coords0"][:, :1], st["flow"][:, :1]), cfg=_CFG["head"])
+            return
         c8.conv2d_c8([self.hc8[0]], fh.conv1, relu=True, out=self.hidden, cfg=_CFG["head"])
         _conv.conv2d_accumulate(self.hidden, _leading_outputs(fh.conv2, 1), st["coords1"][:, :1],
                                 diff=(st["coords0"][:, :1], st["flow"][:, :1]))

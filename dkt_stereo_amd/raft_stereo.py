@@ -444,8 +444,7 @@ class RAFTStereo(nn.Module):
                 g = torch.cuda.CUDAGraph()
                 with capture_graph(g):
                     lp.unit(st)
-                lp.graph = g
-                done = 2
+                lp.graph = g                 # (capturing does not execute: still one unit done)
             for _ in range(iters - done):
                 replay_graph(lp.graph)
             return .25 * conv2d(conv2d(st["net"][0], ub.mask[0], relu=True), ub.mask[2])
@@ -482,7 +481,7 @@ class RAFTStereo(nn.Module):
             st["coords1"].add_(flow_init)
         if self.use_c8 and iters >= 3:
             from . import loop_c8
-            if loop_c8.eligible(self):
+            if loop_c8.eligible(self, st["net"][0].shape):
                 up_mask = self._iterate_c8(st, iters)
                 flow = st["coords1"] - st["coords0"]
                 return flow, self.upsample_flow(flow, up_mask)[:, :1]

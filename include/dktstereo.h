@@ -414,7 +414,8 @@ int dkt_act_c8_pack(const float *x, long x_bstride, void *dst, long dst_bstride_
 int dkt_act_c8_unpack(const void *src, long src_bstride_bytes, float *y, long y_bstride, int B, int C, int H, int W,
                       int ch0, float scale, int device, void *stream);
 /* weights (Cout, sum(src_channels), 3, 3) fp32 -> the kernel's step images [chunk][tap][co/64][hi|lo][k/8][64][8] fp16
- * (every source padded to a multiple of 16 channels, Cout to 64); `scale` a power of two as for dkt_conv2d_pack_weights. */
+ * (every source padded to a multiple of 16 channels, Cout to 64) followed by 12 KB of slack the kernel may read (zero it);
+ * `scale` a power of two as for dkt_conv2d_pack_weights. */
 long dkt_conv_c8_packed_bytes(const int *src_channels, int nsrc, int Cout);
 int dkt_conv_c8_pack_weights(const float *w, const int *src_channels, int nsrc, int Cout, float scale,
                              void *packed, int device, void *stream);
@@ -428,7 +429,9 @@ typedef struct dkt_conv_c8_desc {
     float out_scale;                        /* 1 / (weight scale * activation scale of the sources) */
     float act_scale;                        /* power of two applied to C8S OUTPUTS before the split */
     int B, H, W, Cout, relu;
-    int epilogue;                           /* 0 plain, 1 ConvGRU z|r gates, 2 ConvGRU state update (as dkt_conv_desc) */
+    int epilogue;                           /* 0 plain, 1 ConvGRU z|r gates, 2 ConvGRU state update (as dkt_conv_desc),
+                                             * 3 flow / disparity head (core/update.py:6-14): relu(conv1(x)) is reduced against conv2's
+                                             *   weights per tap instead of being written (cfg 1 or 2); finish with dkt_head_finish */
     float *out; long out_bstride;           /* fp32 NCHW destination (optional when out_c8 is given; epilogue 1: z) */
     void *out_c8; long out_c8_bstride;      /* C8S destination (optional), bytes per batch item; epilogue 2: h' */
     int out_c8_ch0;                         /* first channel written (multiple of 8) */
@@ -440,11 +443,19 @@ typedef struct dkt_conv_c8_desc {
     int out2_c8_ch0;
     const float *tail; long tail_bstride;   /* epilogue 0 + out_c8: channels Cout .. Cout+tail_channels-1 of the C8S output are */
     int tail_channels;                      /* copied from this fp32 NCHW tensor: torch.cat([out, flow]) of core/update.py:85 */
+    const float *head_w;                    /* epilogue 3: weights of the head's SECOND 3x3 layer, [outputs][Cout][12] (9 taps + pad) */
+    float *head_out; long head_out_bstride; /*   planes [B][(output * blocks + block) * 9 + tap][H][W], blocks = dkt_conv2d_c8_head_blocks */
+    int head_outputs;                       /*   1 (stereo: x only / disparity) or 2 */
     int f32_c4;                             /* 1: out, out2, e0, e1, h are "C4" tensors [B][ceil(C/4)][H][W][4] (one 16-byte access per
                                              * lane and channel quad in the epilogue) instead of NCHW; bstrides stay in floats */
 } dkt_conv_c8_desc;
 /* cfg: 0 = tile shape by layer / image size, 1..5 force one (conv_c8.hip c8_dispatch). */
 int dkt_conv2d_c8(const dkt_conv_c8_desc *d, int cfg, int device, void *stream);
+/* FlowHead.conv2 from epilogue 3's planes, added to `target` (raft_stereo.py:165-168), optionally diff_out = target - diff_ref */
+int dkt_conv2d_c8_head_blocks(int Cout, int cfg);
+int dkt_head_finish(const float *planes, long planes_bstride, int n_co, const float *bias, float *target,
+                    long target_bstride, const float *diff_ref, long diff_ref_bstride, float *diff_out,
+                    long diff_out_bstride, int B, int nout, int H, int W, int device, void *stream);
 /* two independent convolutions in one launch (the coarsest GRU rides with the finest); cfg != 0 */
 int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_desc *d1, int cfg, int device, void *stream);
 

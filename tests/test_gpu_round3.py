@@ -1,0 +1,213 @@
+"""-m gpu: the round-3 path -- the C8S convolution (csrc/conv_c8.hip), its producers and the loop built on them.
+
+Oracles: an fp64 convolution of the same operands (bound 3e-6 relative: the split-fp16 arithmetic's class, the round-2
+kernel measures 1.6-1.9e-6), the round-2 kernels (same arithmetic in another accumulation order), torch's own
+resampling operators (bit-exact: the kernels restate ATen's operation order), and the reference fixtures through the full
+model (final disparity <= 1e-3, north_star).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _cases
+import _synth
+from test_gpu_parity import DEV, G, _raft, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+def _c8():
+    from dkt_stereo_amd import conv_c8
+    return conv_c8
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [(1, 40, 72), (2, 50, 70), (1, 184, 312)])
+def test_c8s_pack_roundtrip_and_border(shape):
+    """fp32 -> C8S -> fp32 keeps 22 significant bits; the border and the padding channels stay zero."""
+    c8 = _c8()
+    B, H, W = shape
+    torch.manual_seed(0)
+    x = torch.randn(B, 70, H, W, device=DEV) * torch.logspace(-3, 3, 70, device=DEV).view(1, 70, 1, 1)
+    a = c8.pack(x)
+    assert a.t.shape[1] == 2 * 5 and a.t.shape[3:] == (c8.c8_dims(H, W)[0], c8.c8_dims(H, W)[1], 8)
+    y = c8.unpack(a)
+    # 22 significant bits above 2^-3, an absolute resolution of 2^-25 below (conv.py's stated range of the split operands)
+    assert float(((y - x).abs() / x.abs().clamp_min(2.0 ** -3)).max()) <= 2.0 ** -21
+    t = a.t.clone()
+    t[:, :, :, 1:H + 1, 1:W + 1, :] = 0
+    assert float(t.abs().max()) == 0.0
+    # channels 70..79 of the last group are padding
+    assert float(a.t[:, 8:, :, :, :, 6:].abs().max()) == 0.0
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("case", [
+    (1, 64, 96, [128, 128, 128], 256), (1, 184, 312, [128, 128, 128], 256), (1, 184, 312, [128, 128, 128], 128),
+    (1, 184, 312, [64, 64], 126), (1, 92, 156, [128, 128, 128], 256), (1, 46, 78, [128, 128], 256),
+    (2, 50, 70, [64], 64), (1, 33, 37, [16, 48], 40), (3, 17, 100, [80], 200)])
+def test_conv_c8_matches_fp64_for_every_tile_shape(case):
+    """conv(cat(srcs)) on the C8S kernel, every tile configuration, fp32 NCHW and C8S destinations, vs an fp64 convolution."""
+    c8 = _c8()
+    B, H, W, chs, cout = case
+    torch.manual_seed(1)
+    xs = [torch.randn(B, c, H, W, device=DEV) for c in chs]
+    layer = torch.nn.Conv2d(sum(chs), cout, 3, padding=1).to(DEV)
+    ref = F.conv2d(torch.cat(xs, 1).double(), layer.weight.double(), layer.bias.double(), padding=1)
+    acts = [c8.pack(x) for x in xs]
+    for cfg in (0, 1, 2, 3, 4, 5, 6):
+        for relu in (False, True):
+            want = ref.clamp_min(0) if relu else ref
+            y = c8.conv2d_c8(acts, layer, relu=relu, cfg=cfg)
+            oc = c8.ActC8(B, cout, H, W, DEV)
+            c8.conv2d_c8(acts, layer, relu=relu, out_c8=oc, cfg=cfg)
+            e1, e2 = _rel(y, want), _rel(c8.unpack(oc), want)
+            assert e1 <= 3e-6 and e2 <= 3e-6, (case, cfg, relu, e1, e2)
+            t = oc.t.clone()
+            t[:, :, :, 1:H + 1, 1:W + 1, :] = 0
+            assert float(t.abs().max()) == 0.0, "C8S border written"
+
+
+@torch.no_grad()
+def test_conv_c8_gates_tail_and_pair_match_round2_kernels():
+    """ConvGRU gate epilogues (NCHW and C4 operands), the motion encoder's cat tail and two problems per launch, against the
+    round-2 kernels (same arithmetic, another accumulation order: <= 3e-6 relative)."""
+    from dkt_stereo_amd import conv
+    c8 = _c8()
+    torch.manual_seed(2)
+    B, H, W = 1, 96, 160
+    h = torch.tanh(torch.randn(B, 128, H, W, device=DEV))
+    x1, x2 = torch.randn(B, 128, H, W, device=DEV), torch.randn(B, 128, H, W, device=DEV)
+    cz, cr, cq = (torch.randn(B, 128, H, W, device=DEV) for _ in range(3))
+    zr = torch.nn.Conv2d(384, 256, 3, padding=1).to(DEV)
+    ql = torch.nn.Conv2d(384, 128, 3, padding=1).to(DEV)
+    z0, rh0 = conv.conv2d_gate_zr([h, x1, x2], zr, cz, cr, h)
+    hn0 = conv.conv2d_gate_out([rh0, x1, x2], ql, cq, z0, h)
+    ah, a1, a2 = c8.pack(h), c8.pack(x1), c8.pack(x2)
+    for cfg_zr, cfg_q in ((1, 2), (2, 3), (4, 4), (6, 6)):
+        rh_c8, rh = c8.ActC8(B, 128, H, W, DEV), torch.empty_like(h)
+        z = c8.gate_zr([ah, a1, a2], zr, cz, cr, h, rh_c8=rh_c8, rh=rh, cfg=cfg_zr)
+        hn, hn_c8 = torch.empty_like(h), c8.ActC8(B, 128, H, W, DEV)
+        c8.gate_out([rh_c8, a1, a2], ql, cq, z, h, hn, out_c8=hn_c8, cfg=cfg_q)
+        errs = (_rel(z, z0), _rel(rh, rh0), _rel(c8.unpack(rh_c8), rh0), _rel(hn, hn0), _rel(c8.unpack(hn_c8), hn0))
+        assert max(errs) <= 3e-6, (cfg_zr, cfg_q, errs)
+    # C4 operands
+    h4, cz4, cr4, cq4 = (c8.to_c4(t) for t in (h, cz, cr, cq))
+    rh_c8 = c8.ActC8(B, 128, H, W, DEV)
+    z4 = c8.gate_zr([ah, a1, a2], zr, cz4, cr4, h4, rh_c8=rh_c8, cfg=1, f32_c4=True)
+    hn4 = torch.empty_like(h4)
+    c8.gate_out([rh_c8, a1, a2], ql, cq4, z4, h4, hn4, cfg=2, f32_c4=True)
+    assert _rel(c8.from_c4(z4), z0) <= 3e-6 and _rel(c8.from_c4(hn4), hn0) <= 3e-6
+    # in-place state update (out aliases h), as the loop uses it
+    h2 = h.clone()
+    c8.gate_out([rh_c8, a1, a2], ql, cq, z0, h2, h2, cfg=2)
+    assert _rel(h2, hn0) <= 3e-6
+    # tail = torch.cat([out, flow]) (core/update.py:85)
+    enc = torch.nn.Conv2d(128, 126, 3, padding=1).to(DEV)
+    c1, f1, flow = torch.randn(B, 64, H, W, device=DEV), torch.randn(B, 64, H, W, device=DEV), torch.randn(B, 2, H, W, device=DEV)
+    mf = c8.ActC8(B, 128, H, W, DEV)
+    c8.conv2d_c8([c8.pack(c1), c8.pack(f1)], enc, relu=True, out_c8=mf, tail=flow)
+    want = torch.cat([conv.conv2d([c1, f1], enc, relu=True), flow], 1)
+    assert _rel(c8.unpack(mf), want) <= 3e-6
+    # two problems in one launch == two launches (bit-identical: same kernel, same tiles)
+    xs, hs = torch.randn(1, 256, 24, 40, device=DEV), torch.tanh(torch.randn(1, 128, 24, 40, device=DEV))
+    czs, crs = torch.randn(1, 128, 24, 40, device=DEV), torch.randn(1, 128, 24, 40, device=DEV)
+    zr2 = torch.nn.Conv2d(384, 256, 3, padding=1).to(DEV)
+    ahs, axs = c8.pack(hs), c8.pack(xs)
+    za, zb = torch.empty_like(h), torch.empty_like(hs)
+    ra, rb = c8.ActC8(B, 128, H, W, DEV), c8.ActC8(1, 128, 24, 40, DEV)
+    da = c8.desc([ah, a1, a2], zr, out=za, epilogue=1, e0=cz, e1=cr, h=h, out2_c8=ra)
+    db = c8.desc([ahs, axs], zr2, out=zb, epilogue=1, e0=czs, e1=crs, h=hs, out2_c8=rb)
+    c8.launch_pair(da, db, za, 1)
+    rb1 = c8.ActC8(1, 128, 24, 40, DEV)
+    zb1 = c8.gate_zr([ahs, axs], zr2, czs, crs, hs, rh_c8=rb1, cfg=1)
+    ra1 = c8.ActC8(B, 128, H, W, DEV)
+    za1 = c8.gate_zr([ah, a1, a2], zr, cz, cr, h, rh_c8=ra1, cfg=1)
+    assert torch.equal(za, za1) and torch.equal(zb, zb1) and torch.equal(ra.t, ra1.t) and torch.equal(rb.t, rb1.t)
+
+
+@torch.no_grad()
+def test_c8s_producers_match_their_fp32_twins():
+    """pool2x / interp / 7x7 stem / lookup+convc1 writing C8S directly == the fp32 kernels followed by the split."""
+    from dkt_stereo_amd import conv
+    from dkt_stereo_amd.corr import CorrBlock1D
+    from dkt_stereo_amd.update import interp, pool2x
+    c8 = _c8()
+    torch.manual_seed(3)
+    B, H, W = 2, 46, 78
+    x = torch.randn(B, 128, H, W, device=DEV)
+    big = torch.randn(B, 128, 92, 156, device=DEV)
+    p = c8.pool2x_c8(big, c8.ActC8(B, 128, H, W, DEV))
+    assert torch.equal(p.t, c8.pack(pool2x(big)).t)
+    assert torch.equal(pool2x(big), F.avg_pool2d(big, 3, stride=2, padding=1))
+    u = c8.interp_c8(x, c8.ActC8(B, 128, 92, 156, DEV))
+    assert torch.equal(u.t, c8.pack(interp(x, big)).t)
+    stem = torch.nn.Conv2d(2, 64, 7, padding=3).to(DEV)
+    flow = torch.randn(B, 2, 92, 156, device=DEV) * 5
+    s = c8.stem7_c8(flow, stem, c8.ActC8(B, 64, 92, 156, DEV))
+    assert torch.equal(s.t, c8.pack(conv.conv2d(flow, stem, relu=True)).t)
+    f1, f2 = torch.randn(B, 256, 40, 96, device=DEV), torch.randn(B, 256, 40, 96, device=DEV)
+    blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+    xs = torch.arange(96, device=DEV, dtype=torch.float32).view(1, 1, 1, 96).expand(B, 1, 40, 96)
+    ys = torch.arange(40, device=DEV, dtype=torch.float32).view(1, 1, 40, 1).expand(B, 1, 40, 96)
+    coords = torch.cat([xs - 30 * torch.rand(B, 1, 40, 96, device=DEV), ys], 1).contiguous()
+    c1 = torch.nn.Conv2d(36, 64, 1).to(DEV)
+    got = blk.lookup_conv1x1(coords, c1, out_c8=c8.ActC8(B, 64, 40, 96, DEV))
+    assert got is not None and torch.equal(got.t, c8.pack(blk.lookup_conv1x1(coords, c1)).t)
+
+
+@torch.no_grad()
+def test_fused_flow_head_matches_two_layers():
+    """FlowHead with conv1's ReLU output reduced against conv2's taps in conv1's epilogue (x output only) == conv2(relu(conv1(h)))
+    on the exact kernels, including the coordinate update and flow = coords1 - coords0 of raft_stereo.py:165-168."""
+    from dkt_stereo_amd import conv
+    from dkt_stereo_amd.update import FlowHead, _leading_outputs
+    c8 = _c8()
+    torch.manual_seed(4)
+    for (B, H, W) in ((1, 184, 312), (2, 45, 70)):
+        fh = FlowHead(128, 256, 2).to(DEV)
+        h = torch.tanh(torch.randn(B, 128, H, W, device=DEV))
+        coords0 = torch.randn(B, 2, H, W, device=DEV) * 10
+        want_c = coords0.clone() + 1.5
+        want_d = conv.conv2d(conv.conv2d(h, fh.conv1, relu=True), _leading_outputs(fh.conv2, 1))
+        want_c[:, :1] += want_d
+        for cfg in (2,):
+            coords1 = coords0.clone() + 1.5
+            flow = torch.zeros(B, 2, H, W, device=DEV)
+            c8.head([c8.pack(h)], fh.conv1, _leading_outputs(fh.conv2, 1), coords1[:, :1], diff=(coords0[:, :1], flow[:, :1]), cfg=cfg)
+            assert float((coords1 - want_c).abs().max()) <= 2e-5 * max(1.0, float(want_d.abs().max()))
+            assert torch.equal(flow[:, :1], coords1[:, :1] - coords0[:, :1])
+            assert torch.equal(coords1[:, 1:], want_c[:, 1:])
+
+
+@torch.no_grad()
+def test_raft_c8_loop_matches_round2_loop_and_fixture(golden):
+    """The whole forward at the benchmark workload on the C8S loop: within 1e-3 of the reference fixture, within 2e-4 of the
+    round-2 loop, graph replay == first (eager + captured) forward, and a second pair through the same captured state."""
+    c = _cases.E2E_CASES["736x1248_it32"]
+    model, _ = _raft()
+    i1, i2 = (G(t) for t in _synth.image_pair(c["seed"], 1, c["H"], c["W"], c["shift"]))
+    g = golden("raft_e2e")
+    s = int(g["736x1248_it32/stride"])
+    model.use_c8 = True
+    _, up_first = model(i1, i2, iters=c["iters"], test_mode=True)
+    _, up_replay = model(i1, i2, iters=c["iters"], test_mode=True)
+    assert model._graph_state.get("c8") is not None, "the C8S loop did not run"
+    assert torch.equal(up_first, up_replay)
+    d_ref = maxabs(up_replay[:, :, ::s, ::s], g["736x1248_it32/flow_up"])
+    model.use_c8 = False
+    _, up_r2 = model(i1, i2, iters=c["iters"], test_mode=True)
+    d_r2 = maxabs(up_replay, up_r2)
+    print("C8S loop: vs reference fixture %.3e, vs round-2 loop %.3e" % (d_ref, d_r2))
+    assert d_ref <= 1e-3 and d_r2 <= 2e-4
+    # another pair, then the first one again, through the same captured graph
+    model.use_c8 = True
+    j1, j2 = (G(t) for t in _synth.image_pair(11, 1, c["H"], c["W"], 20))
+    model(j1, j2, iters=c["iters"], test_mode=True)
+    _, up_again = model(i1, i2, iters=c["iters"], test_mode=True)
+    assert torch.equal(up_again, up_replay)
