@@ -52,12 +52,16 @@ def parse():
     p.add_argument("--height", type=int, default=736)
     p.add_argument("--width", type=int, default=1248)
     p.add_argument("--iters", type=int, default=32)
-    p.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
+    p.add_argument("--batch", type=int, default=None,
+                   help="pairs per GPU per step (default 1; with --gpus > 1: 8 = BASELINE.json configs[3], batch 64 over 8 GPUs)")
     p.add_argument("--cpu-iters", type=int, default=6, help="GRU iterations timed by the CPU baseline sample")
     p.add_argument("--skip-cpu-baseline", action="store_true")
     p.add_argument("--conv-backend", default=None, choices=["f16x3", "f16x2", "f16", "miopen"],
                    help="update-block convolution path (default: the package default, f16x3)")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.batch is None:
+        a.batch = 8 if a.gpus > 1 else 1
+    return a
 
 
 def lookup_bytes_per_launch(n_pixels, L=4, r=4, cout=None):
@@ -179,16 +183,31 @@ def main():
         for _ in range(args.warmup):
             step()
         sync()
+        model.check_finite = False          # no host sync per forward inside the timed region: checked once behind it
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            last = step()
         sync()
         t1 = time.perf_counter()
+        model.check_finite = True
+        if not bool(torch.isfinite(last).all()):
+            raise SystemExit("bench.py: non-finite disparities in the timed region")
 
-        elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+        mine = t1 - t0
+        elapsed = torch.tensor([mine], device=dev, dtype=torch.float64)
+        per_rank = [mine]
         if world > 1:
+            every = [torch.zeros_like(elapsed) for _ in range(world)]
+            dist.all_gather(every, elapsed)
+            per_rank = [float(t.item()) for t in every]
             dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         elapsed = float(elapsed.item())
+        ranks_seen = dist.get_world_size() if world > 1 else 1
+        backend = dist.get_backend() if world > 1 else "none (single process)"
+        if rank != 0:
+            # the instrumented passes below are rank 0's (no collective inside them)
+            dist.destroy_process_group()
+            return
 
         # Per-kernel timing.  The timed steps above replay the GRU iteration from a captured
         # HIP graph, where a single kernel cannot be bracketed by events; the same workload is
@@ -196,7 +215,8 @@ def main():
         # launch of (a) the dominant kernel -- the update-block convolution of the finest GRU,
         # gru08 z|r, 384->256 3x3 -- and (b) the correlation lookup (same stream, same inputs,
         # same kernels).  The cost of an empty event pair is measured and subtracted.
-        model.use_hip_graph = False
+        c8_loop = model._graph_state is not None and model._graph_state.get("c8") is not None
+        model.use_hip_graph = c8_loop        # (the C8S loop runs its units eagerly through model.c8_eager instead)
         look_events.clear()
         conv_events = []
         import dkt_stereo_amd.corr as dcorr
@@ -205,10 +225,10 @@ def main():
         real_fused = dcorr.CorrBlock1D.lookup_conv1x1
         fused_lookup = model.fuse_lookup
 
-        def timed_fused(self_, coords, layer, relu=True, tap=False):
+        def timed_fused(self_, coords, layer, relu=True, tap=False, **kw):
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ea.record()
-            y = real_fused(self_, coords, layer, relu=relu, tap=tap)
+            y = real_fused(self_, coords, layer, relu=relu, tap=tap, **kw)
             eb.record()
             if y is not None:
                 look_events.append((ea, eb))
@@ -231,9 +251,30 @@ def main():
             conv_events.append((ea, eb))
             return y
 
+        # round-3 loop (loop_c8.py): the same kernel is the paired launch gru08 z|r + gru32 z|r of conv_c8_kernel; its
+        # units run eagerly here (model.c8_eager) with an event pair around that launch
+        from dkt_stereo_amd import conv_c8 as dc8
+        real_pair = dc8.launch_pair
+        c8_used = []
+
+        def timed_pair(d0, d1, ref, cfg):
+            big = d0.epilogue == 1 and d0.Cout == 256 and d0.H == h4
+            if not big:
+                return real_pair(d0, d1, ref, cfg)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            real_pair(d0, d1, ref, cfg)
+            eb.record()
+            conv_events.append((ea, eb))
+            c8_used.append((d1.H, d1.W, d1.Cout, sum(d1.src_channels[i] for i in range(d1.nsrc)), cfg))
+
+        dc8.launch_pair = timed_pair
         upd.conv2d_gate_zr = timed_gate_zr
-        step()
+        model.c8_eager = c8_loop
+        model(i1, i2, iters=args.iters, test_mode=True)
         torch.cuda.synchronize()
+        model.c8_eager = False
+        dc8.launch_pair = real_pair
         upd.conv2d_gate_zr = real_gate_zr
         dcorr.CorrBlock1D.lookup_conv1x1 = real_fused
         rs.CORR_IMPLEMENTATIONS = real_impls
@@ -255,7 +296,10 @@ def main():
         if st is not None:
             blk_, c1_ = st["corr"], st["coords1"]
             layer_ = model.update_block.encoder.convc1
-            if fused_lookup:
+            if c8_loop:                    # as the loop calls it: straight into the C8S operand of convc2
+                cor_ = st["c8"].cor
+                one = lambda: blk_.lookup_conv1x1(c1_, layer_, out_c8=cor_)   # noqa: E731
+            elif fused_lookup:
                 one = lambda: blk_.lookup_conv1x1(c1_, layer_)          # noqa: E731
             else:
                 one = lambda: blk_(c1_)                                 # noqa: E731
@@ -287,11 +331,6 @@ def main():
         torch.cuda.synchronize()
         hot_ms = e0.elapsed_time(e1)
 
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
     n_pix = B * h4 * w4
     look_avg_ms = sum(look_ms) / max(len(look_ms), 1)
     alg = lookup_bytes_per_launch(n_pix, cout=64 if fused_lookup else None)
@@ -299,12 +338,19 @@ def main():
     passes = {"f16x3": 3, "f16x2": 2, "f16": 1}.get(_conv.get_backend(), 1)
     conv_avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
     conv_alg_flops = 2.0 * n_pix * 384 * 9 * 256
+    conv_kernel = "conv2d_f16s_kernel (dkt_conv2d_f16s_gate_zr), gru08 z|r 384->256 3x3 + gate epilogue @%dx%d" % (h4, w4)
+    if c8_used:
+        # the paired launch also carries the coarsest GRU's z|r convolution (its tiles ride in the same launch)
+        h2, w2, co2, ci2, cfg2 = c8_used[0]
+        conv_alg_flops += 2.0 * B * h2 * w2 * ci2 * 9 * co2
+        conv_kernel = ("conv_c8_kernel<4,2,4,4> (dkt_conv2d_c8_pair, tile shape %d): gru08 z|r 384->256 3x3 @%dx%d + gru32 z|r "
+                       "%d->%d @%dx%d, gate epilogues, C8S operands" % (cfg2, h4, w4, ci2, co2, h2, w2))
     conv_tflops_exec = passes * conv_alg_flops / (conv_avg_ms * 1e-3) / 1e12 if conv_avg_ms > 0 else 0.0
     # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     # rocprofv3 runs of the same kernels on the same shapes); None when the file is absent
     traffic = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")) else "r02_hbm_traffic.json")) as f:
             traffic = json.load(f)
     except (OSError, ValueError):
         pass
@@ -314,6 +360,9 @@ def main():
         "value": world * B * args.steps / elapsed,
         "unit": "pairs/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
+        "collective_backend": backend,
+        "per_rank_pairs_per_s": [B * args.steps / t for t in per_rank],
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -328,7 +377,8 @@ def main():
                                "corr_implementation=reg, BASELINE.json configs[1]"
                                % (args.height, args.width, h4, w4, args.iters, B),
                    "parallelism": "dp%d (independent pairs per rank, result gather only)" % world,
-                   "conv_backend": conv_backend_name},
+                   "conv_backend": conv_backend_name,
+                   "loop": "C8S convolutions (loop_c8.py)" if c8_used else "round-2 kernels"},
         # dominant kernel (~70 % of a pair): the split-fp16 implicit-GEMM convolution.  It is
         # MFMA-bound; `achieved` counts the fp16 MFMA flops it executes per launch
         # (passes x 2*H*W*Cin*9*Cout; the fp32-equivalent algorithmic figure is 1/passes of it)
@@ -337,7 +387,7 @@ def main():
         # of this shape needs) per launch over the launch time, against the dense fp16 MFMA peak the kernel
         # issues on.  The kernel spends `mfma_passes` fp16 MFMAs per algorithmic product (split operands,
         # fp32-class result): `mfma_issue_frac` = passes x frac is how busy it keeps the matrix pipe.
-        "roofline": {"kernel": "conv2d_f16s_kernel (dkt_conv2d_f16s_gate_zr), gru08 z|r 384->256 3x3 + gate epilogue @%dx%d" % (h4, w4),
+        "roofline": {"kernel": conv_kernel,
                      "bound": "mfma", "achieved": conv_tflops_exec / passes, "peak": FP16_MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": conv_tflops_exec / passes / FP16_MFMA_PEAK_TFLOPS,
                      "frac_algorithmic": conv_tflops_exec / passes / FP16_MFMA_PEAK_TFLOPS,
@@ -351,15 +401,19 @@ def main():
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
         # the kernel BASELINE.json's north_star sets the HBM target for
-        "roofline_lookup": {"kernel": ("corr_feat16_kernel<4,4> (dkt_corr1d_lookup_conv1x1): pyramid lookup fused with "
-                                       "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA") if fused_lookup
+        "roofline_lookup": {"kernel": ("corr_feat16_kernel<4,4> (dkt_corr1d_lookup_conv1x1%s): pyramid lookup fused with "
+                                       "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA" % ("_c8, C8S output" if c8_used else "")) if fused_lookup
                             else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic.get("lookup_conv1x1_b1_bytes" if fused_lookup else "lookup_b1_bytes") if default_shape else None,
                             "traffic_source": traffic.get("source") if default_shape else None,
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
-                            "launches_timed": len(look_ms)},
+                            "launches_timed": len(look_ms),
+                            # the same kernel as the loop runs it (rocprofv3 kernel trace of this command, kept under profiles/)
+                            "in_pipeline_avg_launch_us": traffic.get("lookup_in_pipeline_us") if default_shape else None,
+                            "in_pipeline_frac": (alg / (traffic["lookup_in_pipeline_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                            if default_shape and traffic.get("lookup_in_pipeline_us") else None},
     }
     # EPE against the reference itself (BASELINE.json's "EPE vs ref"): tests/golden/raft_e2e.npz holds the
     # reference's CPU output for this exact workload (seed 3, shift 40, 32 iterations, every 8th pixel)

@@ -422,6 +422,7 @@ class RAFTStereo(nn.Module):
 
     #: round 3: the loop on the C8S convolution (loop_c8.py); DKT_C8=0 keeps the round-2 kernels and schedule
     use_c8 = os.environ.get("DKT_C8", "1") != "0"
+    c8_eager = False
 
     def _iterate_c8(self, st, iters):
         """loop_c8.C8Loop: prologue, `iters` units (the first eagerly, one captured, the rest replayed), mask head."""
@@ -437,7 +438,11 @@ class RAFTStereo(nn.Module):
         with harness(inplace_state=True, side_stream=False):
             lp.prologue(st)
             done = 0
-            if lp.graph is None:
+            if self.c8_eager:                # (bench.py's instrumented pass: every unit as plain launches)
+                for _ in range(iters):
+                    lp.unit(st)
+                done = iters
+            elif lp.graph is None:
                 lp.unit(st)                  # eager once: packs weights, sizes the allocator
                 done = 1
                 torch.cuda.synchronize()
