@@ -86,6 +86,7 @@ SIGNATURES = {
     "dkt_pool_d": [_vp, _vp, _l, _i, _l, _i, _vp],
     "dkt_geo_lookup": [_pp, _pp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_gwc_volume": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _i, _vp],
+    "dkt_gwc_volume_mfma": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _i, _vp],
     "dkt_concat_volume": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _i, _vp],
     "dkt_gru_gate_zr": [_vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _i, _l, _i, _vp],
     "dkt_gru_gate_out": [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _i, _i, _l, _i, _vp],

@@ -24,9 +24,38 @@ def _check_pair(ref, tgt):
     return ref.contiguous(), tgt.contiguous()
 
 
+#: "mfma": the banded matrix product on the exact-fp32 matrix cores (dkt_gwc_volume_mfma) where it applies, else the VALU
+#: kernel; "exact": always the VALU kernel, bit-identical to oracle/dkt_oracle.c's summation order.  DKT_GWC=exact|mfma.
+import os as _os
+GWC_MODE = _os.environ.get("DKT_GWC", "mfma")
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def gwc_mode(mode):
+    """Temporarily select the group-wise correlation kernel: "mfma" (default) or "exact" (VALU, the C oracle's order)."""
+    global GWC_MODE
+    if mode not in ("mfma", "exact"):
+        raise ValueError("gwc_mode: 'mfma' or 'exact'")
+    prev, GWC_MODE = GWC_MODE, mode
+    try:
+        yield
+    finally:
+        GWC_MODE = prev
+
+
 def _gwc_into(ref, tgt, vol, maxdisp, num_groups, bstride):
     B, C, H, W = ref.shape
     assert C % num_groups == 0  # groupwise_correlation, submodule.py:154
+    if GWC_MODE == "mfma":
+        rc = _ffi.lib().dkt_gwc_volume_mfma(ref.data_ptr(), tgt.data_ptr(), vol.data_ptr(), B, C, H, W,
+                                            maxdisp, num_groups, bstride, _ffi.device_of(ref), _ffi.stream_of(ref))
+        if rc == 0:
+            return
+        if rc != -7:                              # DKT_E_UNSUPPORTED: shape outside the MFMA form -> the general kernel
+            _ffi.check(rc, "dkt_gwc_volume_mfma")
     rc = _ffi.lib().dkt_gwc_volume(ref.data_ptr(), tgt.data_ptr(), vol.data_ptr(), B, C, H, W,
                                    maxdisp, num_groups, bstride, _ffi.device_of(ref), _ffi.stream_of(ref))
     _ffi.check(rc, "dkt_gwc_volume")

@@ -195,6 +195,13 @@ int dkt_geo_lookup(const float *const *geo_pyr, const float *const *init_pyr,
 int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
                    int B, int C, int H, int W, int D, int G, long vol_bstride,
                    int device, void *stream);
+/* The same volume as a banded matrix product on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32, gwc_mfma.hip):
+ * an fma chain over the group's channels in ascending order -- within one rounding per product of dkt_gwc_volume's
+ * (and the reference's) sum of rounded products; D = 48, C/G in {4, 8, 12, 16}, W % 4 == 0, 16-byte aligned volume
+ * rows, else DKT_E_UNSUPPORTED (callers fall back to dkt_gwc_volume). */
+int dkt_gwc_volume_mfma(const float *ref, const float *tgt, float *vol,
+                        int B, int C, int H, int W, int D, int G, long vol_batch_stride,
+                        int device, void *stream);
 
 /* Replaces build_concat_volume.  ref_masked = 1: GwcNet semantics
  * (meta_arch/gwcnet/submodules.py:25-36, reference half only where w >= d);

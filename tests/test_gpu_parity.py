@@ -165,7 +165,11 @@ def test_gwc_volume(name, golden, c_oracle):
     from dkt_stereo_amd.submodule import build_gwc_volume
     c = _cases.GWC_CASES[name]
     a, b = _cases.volume_inputs(c)
-    vol = build_gwc_volume(G(a), G(b), c["D"], c["G"])
+    from dkt_stereo_amd import submodule as sm
+    vol = build_gwc_volume(G(a), G(b), c["D"], c["G"])          # default: the MFMA form where it applies (D = 48, C/G % 4 == 0)
+    assert maxabs(vol, golden("volumes")["gwc/" + name]) <= 2e-6
+    with sm.gwc_mode("exact"):
+        vol = build_gwc_volume(G(a), G(b), c["D"], c["G"])
     assert maxabs(vol, golden("volumes")["gwc/" + name]) <= 2e-6
     assert np.array_equal(vol.cpu().numpy(), c_oracle.gwc_volume(a, b, c["D"], c["G"]))  # same order -> bit exact
 
@@ -568,7 +572,10 @@ def test_cgi_norm_correlation_volumes(name, golden, c_oracle):
     c = _cases.NORMCORR_CASES[name]
     a, b = _cases.volume_inputs(c)
     g = golden("pcv_cgi")
-    vol = build_gwc_volume_norm(G(a), G(b), c["D"], c["G"]).cpu().numpy()
+    from dkt_stereo_amd import submodule as sm
+    assert maxabs(build_gwc_volume_norm(G(a), G(b), c["D"], c["G"]), g["normcorr/%s/gwc_norm" % name]) <= 1e-6
+    with sm.gwc_mode("exact"):
+        vol = build_gwc_volume_norm(G(a), G(b), c["D"], c["G"]).cpu().numpy()
     assert maxabs(vol, g["normcorr/%s/gwc_norm" % name]) <= 1e-6
     assert np.array_equal(vol, c_oracle.gwc_volume_norm(a, b, c["D"], c["G"]))    # same order -> bit exact
     if c["G"] == 1:

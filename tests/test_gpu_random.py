@@ -62,8 +62,12 @@ def test_volumes_random(c_oracle, B, G_, cpg, H, W, D, seed):
     C = G_ * cpg
     a = _synth.normal((B, C, H, W), seed, "a")
     b = _synth.normal((B, C, H, W), seed, "b")
-    assert np.array_equal(build_gwc_volume(G(a), G(b), D, G_).cpu().numpy(), c_oracle.gwc_volume(a, b, D, G_))
-    assert np.array_equal(build_gwc_volume_norm(G(a), G(b), D, G_).cpu().numpy(), c_oracle.gwc_volume_norm(a, b, D, G_))
+    from dkt_stereo_amd import submodule as sm
+    with sm.gwc_mode("exact"):
+        assert np.array_equal(build_gwc_volume(G(a), G(b), D, G_).cpu().numpy(), c_oracle.gwc_volume(a, b, D, G_))
+        assert np.array_equal(build_gwc_volume_norm(G(a), G(b), D, G_).cpu().numpy(), c_oracle.gwc_volume_norm(a, b, D, G_))
+    want = c_oracle.gwc_volume(a, b, D, G_)               # default mode (MFMA where the shape allows): one rounding per product
+    assert np.abs(build_gwc_volume(G(a), G(b), D, G_).cpu().numpy() - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
     if C <= 16:
         assert np.array_equal(build_concat_volume(G(a), G(b), D).cpu().numpy(), c_oracle.concat_volume(a, b, D, 1))
         assert np.array_equal(build_concat_volume_igev(G(a), G(b), D).cpu().numpy(), c_oracle.concat_volume(a, b, D, 0))

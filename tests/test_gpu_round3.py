@@ -211,3 +211,30 @@ def test_raft_c8_loop_matches_round2_loop_and_fixture(golden):
     model(j1, j2, iters=c["iters"], test_mode=True)
     _, up_again = model(i1, i2, iters=c["iters"], test_mode=True)
     assert torch.equal(up_again, up_replay)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [(1, 8, 8, 5, 48), (2, 3, 12, 7, 100), (1, 5, 16, 3, 68), (1, 2, 4, 9, 200), (1, 40, 8, 6, 240)])
+def test_gwc_volume_mfma_matches_oracle(shape, c_oracle):
+    """ns-1: the group-wise correlation as a banded product on v_mfma_f32_16x16x4_f32 (gwc_mfma.hip) vs the C oracle
+    (<= 2e-6 x scale: an fma chain against the oracle's sum of rounded products), ragged widths, batches, and inside the
+    64-channel GwcNet buffer (a batch stride larger than the volume)."""
+    from dkt_stereo_amd import _ffi, submodule as sm
+    B, G_, cpg, H, W = shape
+    a = _synth.normal((B, G_ * cpg, H, W), 5, "a")
+    b = _synth.normal((B, G_ * cpg, H, W), 5, "b")
+    want = c_oracle.gwc_volume(a, b, 48, G_)
+    ga, gb = G(a), G(b)
+    vol = torch.full((B, G_ + 3, 48, H, W), 7.0, device=DEV)
+    rc = _ffi.lib().dkt_gwc_volume_mfma(ga.data_ptr(), gb.data_ptr(), vol.data_ptr(), B, G_ * cpg, H, W, 48, G_, vol.stride(0),
+                                        _ffi.device_of(vol), _ffi.stream_of(vol))
+    assert rc == 0
+    got = vol[:, :G_].cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert float((vol[:, G_:] - 7.0).abs().max()) == 0.0            # nothing written behind the G planes
+    with sm.gwc_mode("mfma"):
+        assert torch.equal(sm.build_gwc_volume(ga, gb, 48, G_), vol[:, :G_].contiguous())
+    # shapes outside the MFMA form are refused (the Python wrapper then takes the VALU kernel)
+    v2 = torch.empty((B, G_, 40, H, W), device=DEV)
+    assert _ffi.lib().dkt_gwc_volume_mfma(ga.data_ptr(), gb.data_ptr(), v2.data_ptr(), B, G_ * cpg, H, W, 40, G_, v2.stride(0),
+                                          _ffi.device_of(v2), _ffi.stream_of(v2)) == -7
