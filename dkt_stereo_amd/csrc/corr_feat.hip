@@ -407,6 +407,144 @@ __global__ __launch_bounds__(256) void corr_feat16_kernel(CorrFeatArgs a) {
         }
 }
 
+// Block form (L = 4): a block of four waves owns ONE 64-pixel row segment.  Phase 1: wave g samples level g for the 64
+// pixels (lane = pixel: every window load of the wave is one 256-byte segment of the skewed pyramid -- the 16-pixel form
+// moves the same bytes in 64-byte pieces) and leaves its K values per pixel in LDS.  Phase 2: wave m multiplies the
+// 36 x 64 sample matrix with output channels 16m .. 16m+15 on v_mfma_f32_16x16x4_f32 (k ascending: level-major) and
+// stores them -- C8S: 256 contiguous bytes per 16-pixel tile and half.  At cfg4's batch 8: 76 -> see DESIGN 3.3.
+template <int R>
+__global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
+    constexpr int K = 2 * R + 1;
+    constexpr int PITCH = 65;
+    __shared__ float vs[4 * K * PITCH];
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nseg = (a.W1 + 63) / 64;
+    const long hrow = blockIdx.x / nseg;
+    const int seg0 = (int)(blockIdx.x - hrow * nseg) * 64;
+    const int b = blockIdx.y;
+    {
+        const int w1 = seg0 + lane;
+        const bool live = w1 < a.W1;
+        const int w1c = live ? w1 : a.W1 - 1;
+        const long p = hrow * a.W1 + w1c;
+        const float cx = a.coords_x[(size_t)b * a.coords_bstride + p];
+        const int lv = g;
+        const int wi = a.W2 >> lv;
+        const int qm = (w1c >> lv) % wi;
+        const float *lvl = a.skew.p[lv];
+        const float inv = a.inv_wm1[lv];
+        const float *base = lvl + (((long)b * a.H + hrow) * wi) * (long)a.pitch + w1c;
+        const float xc = __fdiv_rn(cx, (float)(1 << lv));
+        const float wm1 = (float)(wi - 1);
+        const float hwm1 = __fdiv_rn(wm1, 2.0f);
+        DktTap taps[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) taps[k] = cf_tap(__fadd_rn((float)(k - R), xc), wm1, inv, hwm1);
+        const int i0 = cf_clamp_idx(taps[0].fl, wi);
+        float win[K + 1];
+#pragma unroll
+        for (int t = 0; t <= K; ++t) {
+            const int c = i0 + t;
+            const bool in = c >= 0 && c < wi;
+            int sidx = (in ? c : 0) - qm;
+            if (sidx < 0) sidx += wi;
+            const float x = base[(long)sidx * a.pitch];
+            win[t] = in ? x : 0.0f;
+        }
+        bool odd = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) odd |= cf_clamp_idx(taps[k].fl, wi) != i0 + k;
+        float v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = dkt_blend(win[k], win[k + 1], taps[k]);
+        if (__any(odd)) {                     // rare (non-finite coordinates): re-sample the irregular taps one by one
+            auto at = [&](int c) -> float {
+                if (c < 0 || c >= wi) return 0.0f;
+                int sidx = c - qm;
+                if (sidx < 0) sidx += wi;
+                return base[(long)sidx * a.pitch];
+            };
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int ik = cf_clamp_idx(taps[k].fl, wi);
+                if (ik != i0 + k) v[k] = dkt_blend(at(ik), at(ik + 1), taps[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) vs[(g * K + k) * PITCH + lane] = v[k];
+        if (a.tap && live) {
+            float *t = a.tap + (size_t)b * a.tap_bstride + p;
+#pragma unroll
+            for (int k = 0; k < K; ++k) t[(size_t)(g * K + k) * a.HW] = v[k];
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: wave m = g: channels 16m .. 16m+15
+    const int m = g;
+    if (16 * m >= a.Cout) return;             // wave-uniform
+    const int j = lane & 15, q = lane >> 4;
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    constexpr int NS = (4 * K) / 4;           // k steps of 4 (4 K is a multiple of 4)
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+        const int kk = 4 * sidx + q;
+        const int co = 16 * m + j;
+        const float wv = a.w[(long)kk * a.Cout + (co < a.Cout ? co : 0)];
+        const float A = co < a.Cout ? wv : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, vs[kk * PITCH + 16 * t + j], acc[t], 0, 0, 0);
+    }
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 16 * m + 4 * q + r;
+        bv[r] = a.bias ? a.bias[co < a.Cout ? co : a.Cout - 1] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int w1 = seg0 + 16 * t + j;
+        const bool live = w1 < a.W1;
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y[r] = __fadd_rn(acc[t][r], bv[r]);
+            if (a.relu) y[r] = dkt_relu(y[r]);
+            if (16 * m + 4 * q + r >= a.Cout) y[r] = 0.0f;
+        }
+        if (a.out_c8) {
+            unsigned hw[2], lw[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float y0 = y[2 * d] * a.act_scale, y1 = y[2 * d + 1] * a.act_scale;
+                const _Float16 h0 = (_Float16)y0, h1 = (_Float16)y1;
+                union { _Float16 h[2]; unsigned u; } t0, t1;
+                t0.h[0] = h0; t0.h[1] = h1;
+                t1.h[0] = (_Float16)(y0 - (float)h0); t1.h[1] = (_Float16)(y1 - (float)h1);
+                hw[d] = t0.u; lw[d] = t1.u;
+            }
+            const bool even = (q & 1) == 0;
+            const unsigned s0 = __shfl_xor(even ? lw[0] : hw[0], 16), s1 = __shfl_xor(even ? lw[1] : hw[1], 16);
+            const uint4 v = even ? make_uint4(hw[0], hw[1], s0, s1) : make_uint4(s0, s1, lw[0], lw[1]);
+            if (live) {
+                const int grp = ((a.out_c8_ch0 + 16 * m) >> 3) + (q >> 1);
+                char *pb = a.out_c8 + (size_t)b * a.out_c8_bs + ((size_t)(hrow + 1) * a.out_c8_Wp + (w1 + 1)) * 16;
+                *(uint4 *)(pb + (size_t)grp * 2 * a.out_c8_plane + (even ? 0 : a.out_c8_plane)) = v;
+            }
+        } else if (live) {
+            float *ob = a.out + (size_t)b * a.out_bstride + hrow * a.W1 + w1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * m + 4 * q + r;
+                if (co < a.Cout) ob[(size_t)co * a.HW] = y[r];
+            }
+        }
+    }
+}
+
 template <int R>
 static int cf16_launch(CorrFeatArgs a, int B, hipStream_t st) {
     a.nseg = (a.W1 + 15) / 16;
@@ -460,6 +598,16 @@ static int corr_feat_impl(const float *const *skew, const float *coords_x, long 
     a.out_c8_Wp = Wp; a.out_c8_ch0 = out_c8_ch0; a.act_scale = act_scale;
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
+    // four levels: the block form (64-pixel segments); DKT_CORR_FEAT_PX=16 keeps the quarter-wave form
+    static const bool px16 = [] { const char *e = getenv("DKT_CORR_FEAT_PX"); return e && atoi(e) == 16; }();
+    if (L == 4 && !px16) {
+        const long blocks = (long)H * ((W1 + 63) / 64);
+        if (blocks > 0x7fffffffL) return DKT_E_SHAPE;
+        dim3 grid((unsigned)blocks, (unsigned)B);
+        if (r == 4) hipLaunchKernelGGL(corr_feat64_kernel<4>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(corr_feat64_kernel<3>, grid, dim3(256), 0, st, a);
+        return dkt_launch_status();
+    }
     if (out_c8) return r == 4 ? cf16_launch<4>(a, B, st) : cf16_launch<3>(a, B, st);
     // four levels: the 16-pixel form (one level per quarter-wave); DKT_CORR_FEAT_PX=32 forces the half-wave form
     static const bool px32 = [] { const char *e = getenv("DKT_CORR_FEAT_PX"); return e && atoi(e) == 32; }();
