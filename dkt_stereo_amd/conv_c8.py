@@ -271,3 +271,53 @@ def head(srcs, layer1, layer2, target, diff=None, cfg=2):
                            0 if dst is None else dst.stride(0), s0.B, nout, s0.H, s0.W, _ffi.device_of(planes), _ffi.stream_of(planes))
     _ffi.check(rc, "dkt_head_finish")
     return target
+
+
+def residual_c8(srcs, layer, res, relu=True, out=None, out_c8=None, cfg=0):
+    """relu(res + [relu](conv(cat(srcs)) + bias)): the tail of a residual block whose norm is folded into `layer`
+    (core/extractor.py:52-60) in the convolution's epilogue (epilogue 4).  `res`: fp32 NCHW; `out` (fp32 NCHW, may be
+    `res` itself) and / or `out_c8`."""
+    s0 = srcs[0]
+    if out is None and out_c8 is None:
+        out = torch.empty((s0.B, int(layer.weight.shape[0]), s0.H, s0.W), device=s0.device, dtype=torch.float32)
+    d = desc(srcs, layer, relu=relu, out=out, out_c8=out_c8, epilogue=4, e0=res)
+    launch(d, s0.t, cfg)
+    return out if out is not None else out_c8
+
+
+def stem7_dual(x, layer, out, dst, relu=True):
+    """out = [relu](conv7x7(x)) as fp32 NCHW and dst = the same as C8S, one launch (the encoders' first layer,
+    core/extractor.py:140-142 / :167-171 with an eval-mode BatchNorm folded into `layer`)."""
+    from . import conv as _conv
+    B, cin, H, W = x.shape
+    w, b = layer.weight, layer.bias
+    key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+    L = _ffi.lib()
+    with _CACHE_LOCK:
+        pk = _conv._stem7_packed(layer, key, L)
+    in_scale = 2.0 ** _conv.in_exp_of(layer)
+    rc = L.dkt_conv2d_stem7_dual(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
+                                 None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale / in_scale, in_scale,
+                                 out.data_ptr(), out.stride(0), dst.data_ptr(), dst.bstride_bytes, 0, dst.scale,
+                                 B, cin, int(w.shape[0]), H, W, int(bool(relu)), _ffi.device_of(x), _ffi.stream_of(x))
+    _ffi.check(rc, "dkt_conv2d_stem7_dual")
+    return out
+
+
+def norm_join_c8(c, c_params, c_relu=True, a=None, a_params=None, a_relu=False, y=None, dst=None, ch0=0):
+    """t = [relu]((c - mean) * invstd); with `a`: t = relu(a' + t), a' = a or [relu](normalised a) when `a_params` is given
+    (the instance-norm glue of core/extractor.py:21-60) -> fp32 `y` and / or C8S `dst`, one pass (dkt_instance_norm_join_c8).
+    `*_params`: (B*C, 2) (mean, 1/std) from extractor.instance_norm_params."""
+    B, C, H, W = c.shape
+    if not c.is_contiguous() or (a is not None and (not a.is_contiguous() or a.shape != c.shape)) \
+            or (y is not None and (not y.is_contiguous() or y.shape != c.shape)):
+        raise ValueError("norm_join_c8: dense fp32 NCHW tensors of one shape")
+    if dst is not None and (dst.H, dst.W, dst.B) != (H, W, B):
+        raise ValueError("norm_join_c8: C8S destination of another size")
+    rc = _ffi.lib().dkt_instance_norm_join_c8(
+        c.data_ptr(), c_params.data_ptr(), int(bool(c_relu)), None if a is None else a.data_ptr(),
+        None if a_params is None else a_params.data_ptr(), int(bool(a_relu)), None if y is None else y.data_ptr(),
+        None if dst is None else dst.data_ptr(), 0 if dst is None else dst.bstride_bytes, ch0,
+        1.0 if dst is None else dst.scale, B, C, H, W, _ffi.device_of(c), _ffi.stream_of(c))
+    _ffi.check(rc, "dkt_instance_norm_join_c8")
+    return y if y is not None else dst

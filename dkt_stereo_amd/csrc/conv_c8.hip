@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                             }
                         } else {
                             float gc[4], gh[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
-                            f32_load4(f32_ptr(pc, cl, px, iHW), iHW, gc);
+                            f32_load4(f32_ptr(pc, cl < cout_eff ? cl : 0, px, iHW), iHW, gc);
                             if (ph) f32_load4(f32_ptr(ph, cl, px, iHW), iHW, gh);
                             if (pz) f32_load4(f32_ptr(pz, cl, px, iHW), iHW, gz);
 #pragma unroll
@@ -424,6 +424,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                                 if (a.epi == 1) {
                                     const float g = c8_sigmoid(__fadd_rn(x[i], gc[i]));
                                     v[jj][i] = rpart ? __fmul_rn(g, gh[i]) : g;
+                                } else if (a.epi == 4) {
+                                    // residual join of core/extractor.py:52-60: relu(x + [relu](conv + bias)); padded channels stay 0
+                                    const float t = a.relu ? dkt_relu(x[i]) : x[i];
+                                    v[jj][i] = cl < a.Cout ? dkt_relu(__fadd_rn(gc[i], t)) : 0.0f;
                                 } else {
                                     const float q = c8_tanh(__fadd_rn(x[i], gc[i]));
                                     v[jj][i] = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, gz[i]), gh[i]), __fmul_rn(gz[i], q));
@@ -777,7 +781,7 @@ static int c8_fill(C8Args &a, const dkt_conv_c8_desc *d) {
     if (d->nsrc < 1 || d->nsrc > C8_MAX_SRC || d->B <= 0 || d->B > 65535 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return DKT_E_SHAPE;
     if (!d->w || (!d->out && !d->out_c8 && d->epilogue != 1 && d->epilogue != 3)) return DKT_E_NULL;
     if (!(d->out_scale > 0.0f) || !(d->act_scale > 0.0f)) return DKT_E_SHAPE;
-    if (d->epilogue < 0 || d->epilogue > 3) return DKT_E_UNSUPPORTED;
+    if (d->epilogue < 0 || d->epilogue > 4) return DKT_E_UNSUPPORTED;
     int Hp, Wp;
     dkt_act_c8_dims(d->H, d->W, &Hp, &Wp);
     a.nchunks = 0;
@@ -818,6 +822,9 @@ static int c8_fill(C8Args &a, const dkt_conv_c8_desc *d) {
     } else if (a.epi == 2) {
         if (!d->e0 || !d->e1 || !d->h) return DKT_E_NULL;
         if (d->Cout % 64 != 0) return DKT_E_UNSUPPORTED;
+    } else if (a.epi == 4) {
+        if (!d->e0) return DKT_E_NULL;
+        if (d->Cout % 4 != 0) return DKT_E_UNSUPPORTED;
     }
     if (a.tail && (a.epi != 0 || !a.out_c8 || a.tail_ch <= 0 || a.Cout + a.tail_ch > a.n_co64 * 64)) return DKT_E_UNSUPPORTED;
     a.tiles_w = a.tiles_xy = a.n_co = a.total_tiles = 0;

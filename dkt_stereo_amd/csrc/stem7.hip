@@ -227,3 +227,12 @@ extern "C" int dkt_conv2d_stem7_c8(const float *x, long x_bstride, const void *w
     return stem7_impl(x, x_bstride, w_hi, w_lo, bias, out_scale, in_scale, nullptr, 0, y_c8, y_c8_bstride_bytes, y_c8_ch0,
                       act_scale, B, Cin, Cout, H, W, relu, device, stream);
 }
+
+extern "C" int dkt_conv2d_stem7_dual(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
+                                     const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
+                                     void *y_c8, long y_c8_bstride_bytes, int y_c8_ch0, float act_scale,
+                                     int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream) {
+    if (!y || !y_c8) return DKT_E_NULL;
+    return stem7_impl(x, x_bstride, w_hi, w_lo, bias, out_scale, in_scale, y, y_bstride, y_c8, y_c8_bstride_bytes, y_c8_ch0,
+                      act_scale, B, Cin, Cout, H, W, relu, device, stream);
+}

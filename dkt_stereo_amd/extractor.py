@@ -23,6 +23,17 @@ FUSE_ENCODER = os.environ.get("DKT_FUSE_ENCODER", "1") != "0"
 CNET_STREAMS = os.environ.get("DKT_CNET_STREAMS", "1") != "0"
 
 
+#: DKT_C8_ENCODER=1: the full-resolution stage (conv1 + layer1) on conv_c8.  Opt-in: the 64 -> 64 convolutions themselves
+#: drop from 270-300 to 205-215 us per image at 736 x 1248, but the fp32 residual traffic of the join epilogue (batch-norm
+#: encoder) and the normalise-to-C8S passes (instance-norm encoder) give the gain back: 6.2 -> 6.5 ms fnet, 2.5 -> 2.6 ms
+#: cnet (profiles/r03_encoder_c8.txt)
+C8_ENCODER = os.environ.get("DKT_C8_ENCODER", "0") == "1"
+#: full-resolution pixels from which layer1 takes the C8S path (its tiles are 8 rows x 32 columns; smaller images leave CUs idle)
+C8_ENCODER_MIN_PIXELS = int(os.environ.get("DKT_C8_ENCODER_MIN_PIXELS", "100000"))
+#: tile shape of the 64 -> 64 layers (conv_c8.hip c8_dispatch)
+C8_ENCODER_CFG = int(os.environ.get("DKT_C8_ENCODER_CFG", "3"))
+
+
 def _hip_ok(x):
     return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
 
@@ -277,7 +288,80 @@ class _Trunk(nn.Module):
         self.layer2 = _stage(64, 96, norm_fn, 1 + (downsample > 1))
         self.layer3 = _stage(96, 128, norm_fn, 1 + (downsample > 0))
 
+    def _layer1_c8_kind(self, x):
+        """'batch' / 'instance' when conv1 + layer1 can run on the C8S convolution (conv_c8.hip): stride-1 stem, two plain
+        64 -> 64 residual blocks, one norm kind throughout (folded eval-mode BatchNorm, or affine-free instance norm)."""
+        from . import conv as _conv
+        if not (C8_ENCODER and FUSE_ENCODER and torch.is_tensor(x) and x.dim() == 4 and _hip_ok(x)):
+            return None
+        if x.shape[1] > 4 or x.shape[2] * x.shape[3] < C8_ENCODER_MIN_PIXELS or _conv.get_backend() != "f16x3":
+            return None
+        convs = [self.conv1] + [c for b in self.layer1 for c in (b.conv1, b.conv2)]
+        norms = [self.norm1] + [n for b in self.layer1 for n in (b.norm1, b.norm2)]
+        if (self.conv1.stride != (1, 1) or tuple(self.conv1.weight.shape[2:]) != (7, 7) or self.conv1.padding != (3, 3)
+                or self.conv1.weight.shape[0] != 64 or any(b.downsample is not None for b in self.layer1)):
+            return None
+        if any(getattr(c, "dkt_in_exp", 0) or c.padding_mode != 'zeros' or (torch.is_grad_enabled() and c.weight.requires_grad)
+               for c in convs):
+            return None
+        if any(tuple(c.weight.shape) != (64, 64, 3, 3) or c.stride != (1, 1) or c.dilation != (1, 1) or c.groups != 1
+               for c in convs[1:]):
+            return None
+        if all(_plain_instance_norm(n) for n in norms):
+            return 'instance'
+        if all(isinstance(n, nn.BatchNorm2d) and not n.training and n.track_running_stats for n in norms):
+            return 'batch'
+        return None
+
+    def _c8_buffers(self, x):
+        """Two C8S tensors of the full-resolution stage, kept between calls (their zero border is written once)."""
+        from . import conv_c8 as c8
+        B, _, H, W = x.shape
+        if torch.cuda.is_current_stream_capturing():
+            return c8.ActC8(B, 64, H, W, x.device), c8.ActC8(B, 64, H, W, x.device)
+        key = (B, H, W, str(x.device))
+        with _CACHE_LOCK:
+            cache = self.__dict__.setdefault("_dkt_c8_buf", {})
+            hit = cache.get(str(x.device))
+            if hit is None or hit[0] != key:
+                hit = cache[str(x.device)] = (key, c8.ActC8(B, 64, H, W, x.device), c8.ActC8(B, 64, H, W, x.device))
+        return hit[1], hit[2]
+
+    def _layer1_c8(self, x, kind):
+        """conv1 / norm1 / relu + layer1 (core/extractor.py:140-146, :167-173 with ResidualBlock :52-60) on conv_c8: every
+        3x3 layer reads the pre-split C8S operand its producer's epilogue (or the one-pass instance-norm glue) wrote."""
+        from . import conv_c8 as c8
+        x = x if x.is_contiguous() else x.contiguous()
+        A, Bf = self._c8_buffers(x)
+        B, _, H, W = x.shape
+        new = lambda: torch.empty((B, 64, H, W), device=x.device, dtype=torch.float32)
+        cfg = C8_ENCODER_CFG
+        if kind == 'batch':
+            cur = c8.stem7_dual(x, _folded(self.conv1, self.norm1), new(), A, relu=True)
+            for i, blk in enumerate(self.layer1):
+                last = i + 1 == len(self.layer1)
+                c8.conv2d_c8([A], _folded(blk.conv1, blk.norm1), relu=True, out_c8=Bf, cfg=cfg)
+                # the join reads `cur` and writes it in place (each element by the thread that read it)
+                c8.residual_c8([Bf], _folded(blk.conv2, blk.norm2), cur, relu=True, out=cur, out_c8=None if last else A, cfg=cfg)
+            return cur
+        raw0 = conv2d(x, self.conv1)
+        res, res_p = raw0, instance_norm_params(self.norm1, raw0)       # residual operand: relu(norm1(raw0)), evaluated in the join
+        c8.norm_join_c8(raw0, res_p, True, dst=A)
+        for i, blk in enumerate(self.layer1):
+            last = i + 1 == len(self.layer1)
+            c1 = c8.conv2d_c8([A], blk.conv1, out=new(), cfg=cfg)
+            c8.norm_join_c8(c1, instance_norm_params(blk.norm1, c1), True, dst=Bf)
+            c2 = c8.conv2d_c8([Bf], blk.conv2, out=c1, cfg=cfg)      # (c1 has been consumed)
+            y = new()
+            c8.norm_join_c8(c2, instance_norm_params(blk.norm2, c2), True, a=res, a_params=res_p, a_relu=True,
+                            y=y, dst=None if last else A)
+            res, res_p = y, None
+        return res
+
     def _trunk(self, x):
+        kind = self._layer1_c8_kind(x)
+        if kind is not None:
+            return self.layer3(self.layer2(self._layer1_c8(x, kind)))
         if FUSE_ENCODER and _plain_instance_norm(self.norm1) and _hip_ok(x):
             # fnet: the stem's normalise + ReLU pass is folded into its two consumers (layer1.0.conv1's staging, the
             # residual operand of layer1.0's join)

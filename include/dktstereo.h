@@ -438,7 +438,9 @@ typedef struct dkt_conv_c8_desc {
     int B, H, W, Cout, relu;
     int epilogue;                           /* 0 plain, 1 ConvGRU z|r gates, 2 ConvGRU state update (as dkt_conv_desc),
                                              * 3 flow / disparity head (core/update.py:6-14): relu(conv1(x)) is reduced against conv2's
-                                             *   weights per tap instead of being written (cfg 1 or 2); finish with dkt_head_finish */
+                                             *   weights per tap instead of being written (cfg 1 or 2); finish with dkt_head_finish
+                                             * 4 residual join of a residual block whose norm is folded into the weights
+                                             *   (core/extractor.py:52-60): relu(e0 + [relu](conv + bias)), Cout % 4 == 0 */
     float *out; long out_bstride;           /* fp32 NCHW destination (optional when out_c8 is given; epilogue 1: z) */
     void *out_c8; long out_c8_bstride;      /* C8S destination (optional), bytes per batch item; epilogue 2: h' */
     int out_c8_ch0;                         /* first channel written (multiple of 8) */
@@ -479,6 +481,22 @@ int dkt_conv2d_stem7_c8(const float *x, long x_bstride, const void *w_hi, const 
                         const float *bias, float out_scale, float in_scale, void *y_c8, long y_c8_bstride_bytes,
                         int y_c8_ch0, float act_scale, int B, int Cin, int Cout, int H, int W, int relu,
                         int device, void *stream);
+/* the same stem writing fp32 NCHW and C8S at once (the encoders' first layer: the fp32 copy is the residual operand of
+ * layer1, core/extractor.py:167-171) */
+int dkt_conv2d_stem7_dual(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
+                          const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
+                          void *y_c8, long y_c8_bstride_bytes, int y_c8_ch0, float act_scale,
+                          int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream);
+/* Instance-norm glue of the feature encoder (core/extractor.py:21-60 with norm_fn='instance') producing C8S operands:
+ *   t = (c - mean_c) * invstd_c;  if c_relu: t = relu(t);
+ *   if a:  t = relu(a' + t),  a' = a or [relu]((a - mean_a) * invstd_a) when a_mean_invstd is given
+ * c, a: fp32 NCHW (B, C, H, W), dense per batch item; *_mean_invstd: (B*C, 2) from dkt_instance_norm_finalize.
+ * Writes y (fp32 NCHW, optional) and / or channels [ch0, ch0+C) of the C8S tensor dst (optional).  Same arithmetic as
+ * dkt_instance_norm / dkt_instance_norm_add_relu_lazy. */
+int dkt_instance_norm_join_c8(const float *c, const float *c_mean_invstd, int c_relu,
+                              const float *a, const float *a_mean_invstd, int a_relu,
+                              float *y, void *dst, long dst_bstride_bytes, int ch0, float act_scale,
+                              int B, int C, int H, int W, int device, void *stream);
 int dkt_corr1d_lookup_conv1x1_c8(const float *const *skew, const float *coords_x, long coords_bstride,
                                  const float *weight, const float *bias, void *out_c8, long out_c8_bstride_bytes,
                                  int out_c8_ch0, float act_scale, int B, int H, int W1, int W2, int L, int r, int Cout,

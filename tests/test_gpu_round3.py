@@ -238,3 +238,79 @@ def test_gwc_volume_mfma_matches_oracle(shape, c_oracle):
     v2 = torch.empty((B, G_, 40, H, W), device=DEV)
     assert _ffi.lib().dkt_gwc_volume_mfma(ga.data_ptr(), gb.data_ptr(), v2.data_ptr(), B, G_ * cpg, H, W, 40, G_, v2.stride(0),
                                           _ffi.device_of(v2), _ffi.stream_of(v2)) == -7
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [(2, 64, 40, 72), (1, 20, 33, 37)])
+def test_instance_norm_join_c8_matches_torch(shape):
+    """The one-pass instance-norm glue (normalise [+ReLU] [+ residual join]) -> fp32 and C8S, against torch's instance_norm."""
+    from dkt_stereo_amd import extractor as ex
+    c8 = _c8()
+    B, C, H, W = shape
+    torch.manual_seed(3)
+    norm = torch.nn.InstanceNorm2d(C)
+    c = torch.randn(B, C, H, W, device=DEV) * 3 + 1
+    a = torch.randn(B, C, H, W, device=DEV) * 2 - 0.5
+    pc, pa = ex.instance_norm_params(norm, c), ex.instance_norm_params(norm, a)
+    nc, na = F.instance_norm(c.double()), F.instance_norm(a.double())
+    for want, kw in ((nc.clamp_min(0), dict(c_relu=True)),
+                     (nc, dict(c_relu=False)),
+                     ((a.double() + nc.clamp_min(0)).clamp_min(0), dict(c_relu=True, a=a)),
+                     ((na.clamp_min(0) + nc.clamp_min(0)).clamp_min(0), dict(c_relu=True, a=a, a_params=pa, a_relu=True)),
+                     ((na + nc.clamp_min(0)).clamp_min(0), dict(c_relu=True, a=a, a_params=pa, a_relu=False))):
+        y = torch.empty_like(c)
+        d = c8.ActC8(B, C, H, W, DEV)
+        c8.norm_join_c8(c, pc, y=y, dst=d, **kw)
+        assert _rel(y, want) <= 2e-6, kw.keys()
+        # the C8S twin is the split of exactly those fp32 values
+        assert torch.equal(c8.unpack(d), c8.unpack(c8.pack(y)))
+        t = d.t.clone()
+        t[:, :, :, 1:H + 1, 1:W + 1, :] = 0
+        assert float(t.abs().max()) == 0.0
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("case", [(1, 64, 96, 64, 64), (2, 50, 70, 64, 96), (1, 33, 37, 48, 40)])
+def test_conv_c8_residual_epilogue_matches_fp64(case):
+    """Epilogue 4: relu(res + relu(conv + bias)) -> fp32 (in place over res) and C8S, every tile shape."""
+    c8 = _c8()
+    B, H, W, cin, cout = case
+    torch.manual_seed(4)
+    x = torch.randn(B, cin, H, W, device=DEV)
+    res = torch.randn(B, cout, H, W, device=DEV)
+    layer = torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+    want = (res.double() + F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=1).clamp_min(0)).clamp_min(0)
+    a = c8.pack(x)
+    for cfg in (0, 1, 2, 3, 4, 5, 6):
+        r = res.clone()
+        oc = c8.ActC8(B, cout, H, W, DEV)
+        y = c8.residual_c8([a], layer, r, relu=True, out=r, out_c8=oc, cfg=cfg)
+        assert y is r and _rel(y, want) <= 3e-6, (case, cfg, _rel(y, want))
+        assert torch.equal(c8.unpack(oc), c8.unpack(c8.pack(y))), (case, cfg)
+        assert float(oc.t[:, :, :, 0].abs().max()) == 0.0 and float(oc.t[:, :, :, :, 0].abs().max()) == 0.0
+
+
+@torch.no_grad()
+def test_encoder_layer1_on_c8_matches_round2_path(monkeypatch):
+    """conv1 + layer1 of both encoders on conv_c8 (extractor._layer1_c8, DKT_C8_ENCODER=1) against the round-2 kernels:
+    the same split-fp16 arithmetic in another accumulation order."""
+    from dkt_stereo_amd import extractor as ex
+    m, _ = _raft(DEV)
+    torch.manual_seed(5)
+    x = torch.rand(2, 3, 96, 160, device=DEV) * 2 - 1
+    monkeypatch.setattr(ex, "C8_ENCODER", False)
+    f0, c0 = m.fnet._trunk(x), m.cnet._trunk(x[:1])
+    monkeypatch.setattr(ex, "C8_ENCODER", True)
+    monkeypatch.setattr(ex, "C8_ENCODER_MIN_PIXELS", 0)
+    assert m.fnet._layer1_c8_kind(x) == 'instance' and m.cnet._layer1_c8_kind(x[:1]) == 'batch'
+    for cfg in (3, 4):
+        monkeypatch.setattr(ex, "C8_ENCODER_CFG", cfg)
+        f1, c1 = m.fnet._trunk(x), m.cnet._trunk(x[:1])
+        assert _rel(f1, f0) <= 2e-5 and _rel(c1, c0) <= 2e-5, (cfg, _rel(f1, f0), _rel(c1, c0))
+    # the cached C8S buffers are reused by a second call and follow another shape
+    assert torch.equal(m.fnet._trunk(x), f1)
+    x2 = torch.rand(1, 3, 64, 96, device=DEV) * 2 - 1
+    monkeypatch.setattr(ex, "C8_ENCODER", False)
+    g0 = m.fnet._trunk(x2)
+    monkeypatch.setattr(ex, "C8_ENCODER", True)
+    assert _rel(m.fnet._trunk(x2), g0) <= 2e-5
