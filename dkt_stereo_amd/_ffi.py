@@ -50,6 +50,7 @@ class ConvC8Desc(ctypes.Structure):
 
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
+    "dkt_build_ablation": [],
     "dkt_pool2x_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_interp_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_conv2d_stem7_c8": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -145,6 +146,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = RESTYPES.get(name, ctypes.c_int)
             fn.argtypes = argtypes
+        abl = L.dkt_build_ablation()
+        if abl and os.environ.get("DKT_ALLOW_ABLATION") != "1":
+            raise DktError("%s is a timing-only ablation build (mask 0x%x: its convolutions skip work and return wrong "
+                           "results); rebuild with `python -m dkt_stereo_amd.build` (tools set DKT_ALLOW_ABLATION=1)" % (LIB_PATH, abl))
         _lib = L
     return _lib
 

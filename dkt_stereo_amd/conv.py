@@ -235,7 +235,12 @@ def few_eligible(layer):
     cout, cin, kh, kw = layer.weight.shape
     pad = layer.padding
     pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
-    return kh == 3 and kw == 3 and pad == (1, 1) and _stride_of(layer) == (1, 1) and cout <= 4
+    if not (kh == 3 and kw == 3 and pad == (1, 1) and _stride_of(layer) == (1, 1) and cout <= 4):
+        return False
+    # what launch_few (conv_direct.hip) can stage in 160 KB of LDS: 110592 B of patches + 384 B per (8-channel slice, output);
+    # wider layers (Cin > 1104 / 552 / 272 for 1 / 2 / 3-4 outputs) stay on dkt_conv2d_f16s
+    to = 1 if cout <= 1 else 2 if cout <= 2 else 4
+    return 110592 + 384 * ((cin + 7) // 8) * to <= 160 * 1024
 
 
 def _conv2d_direct(x, layer, relu, out):

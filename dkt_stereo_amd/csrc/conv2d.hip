@@ -772,6 +772,16 @@ static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hi
     if (KH == 3) return launch_conv_shape<3, PASSES>(a, B, st, sec);
     return launch_conv_shape<1, PASSES>(a, B, st, sec);
 }
+// the ablation mask each kernel translation unit was compiled with (dkt_build_ablation, abi.hip: the product is 0)
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 1
+int conv2d_abl_p1() { return CONV_ABL; }
+#endif
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 2
+int conv2d_abl_p2() { return CONV_ABL; }
+#endif
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 3
+int conv2d_abl_p3() { return CONV_ABL; }
+#endif
 #if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 1
 int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) { return conv2d_launch_passes<1>(a, B, KH, stride, st, sec); }
 #endif

@@ -920,3 +920,5 @@ extern "C" int dkt_conv2d_c8_head_blocks(int Cout, int cfg) {
     if (cfg == 2) return (n64 + 1) / 2;
     return DKT_E_UNSUPPORTED;
 }
+
+int conv_c8_abl() { return C8_ABL; }      // dkt_build_ablation (abi.hip)

@@ -172,7 +172,14 @@ class LazyNorm:
 
     def __init__(self, norm, raw, relu):
         self.norm, self.raw, self.relu = norm, raw, relu
-        self.params = instance_norm_params(norm, raw)
+        self._params = None
+
+    @property
+    def params(self):
+        """(mean, 1/std) per plane, computed on first use (a consumer that materialises never needs them)."""
+        if self._params is None:
+            self._params = instance_norm_params(self.norm, self.raw)
+        return self._params
 
     def materialize(self):
         return norm_act(self.norm, self.raw, self.relu)
@@ -228,7 +235,9 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         lazy = x if isinstance(x, LazyNorm) else None
-        fuse = FUSE_ENCODER and _hip_ok(lazy.raw if lazy is not None else x)
+        # (trainable weights under autograd: the torch path, as _Conv2d.forward decides layer by layer)
+        fuse = (FUSE_ENCODER and _hip_ok(lazy.raw if lazy is not None else x)
+                and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())))
         if fuse and _plain_instance_norm(self.norm1) and _plain_instance_norm(self.norm2) and fused_eligible(self.conv2, True):
             # fnet: relu(norm1(.)) between the two layers lives in conv2's staging (no normalise pass, the
             # intermediate is read once for its statistics and once by conv2)
@@ -362,7 +371,8 @@ class _Trunk(nn.Module):
         kind = self._layer1_c8_kind(x)
         if kind is not None:
             return self.layer3(self.layer2(self._layer1_c8(x, kind)))
-        if FUSE_ENCODER and _plain_instance_norm(self.norm1) and _hip_ok(x):
+        if (FUSE_ENCODER and _plain_instance_norm(self.norm1) and _hip_ok(x)
+                and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             # fnet: the stem's normalise + ReLU pass is folded into its two consumers (layer1.0.conv1's staging, the
             # residual operand of layer1.0's join)
             x = LazyNorm(self.norm1, self.conv1(x), relu=True)

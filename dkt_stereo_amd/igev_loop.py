@@ -158,6 +158,10 @@ def _fingerprint(update_block):
     fp = [(_conv.get_backend(), FUSE_GATES)]
     for t in update_block.parameters():
         fp.append((t.data_ptr(), t._version))
+    for m in update_block.modules():
+        e = getattr(m, "dkt_in_exp", None)       # calibrated activation exponents are baked into the captured launches
+        if e:
+            fp.append(("in_exp", id(m), e))
     return tuple(fp)
 
 
@@ -174,7 +178,8 @@ def igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, it
 
 def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph, cache):
     n = update_block.args.n_gru_layers
-    pipelined = (use_hip_graph and init_disp.is_cuda and iters >= 3 and n == 3
+    # (conv.calibrate() records activation ranges with host synchronisation: plain loop, every iteration observed)
+    pipelined = (use_hip_graph and not _conv.calibrating() and not getattr(update_block, "_is_replica", False) and init_disp.is_cuda and iters >= 3 and n == 3
                  and not getattr(update_block.args, "slow_fast_gru", False) and update_block.side_stream)
     if not pipelined:
         return _plain(update_block, geo_fn, init_disp, coords, list(net_list), inp_list, iters)

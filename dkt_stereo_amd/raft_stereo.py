@@ -128,7 +128,7 @@ class RAFTStereo(nn.Module):
     def encode(self, image1, image2):
         """raft_stereo.py:91-116: normalisation, encoders, context split.  With the captured graph the returned
         tensors are the graph's static outputs: valid until the next encode() on this thread."""
-        if (self.use_hip_graph and self.graph_encoders and image1.is_cuda and image1.dtype == torch.float32
+        if (self.use_hip_graph and self.graph_encoders and not getattr(self, "_is_replica", False) and image1.is_cuda and image1.dtype == torch.float32
                 and image2.dtype == torch.float32 and image1.shape == image2.shape
                 and not torch.is_grad_enabled() and not _conv.calibrating()):
             return self._encode_graphed(image1, image2)
@@ -523,7 +523,11 @@ class RAFTStereo(nn.Module):
         then `iters` x (lookup, update block), then convex upsampling."""
         args = self.args
         n = args.n_gru_layers
-        if (self.use_hip_graph and iters >= 3 and fmap1.is_cuda and args.corr_implementation == "reg"
+        # conv.calibrate() records activation ranges with a host synchronisation per layer: the plain loop (no stream capture,
+        # every iteration observed) serves it
+        # nn.DataParallel replicas are new modules with new parameter tensors (and new threads) on every forward: a captured
+        # loop would be re-captured each time -- they run the plain loop; graph replay needs ONE persistent module per device
+        if (self.use_hip_graph and not getattr(self, "_is_replica", False) and not _conv.calibrating() and iters >= 3 and fmap1.is_cuda and args.corr_implementation == "reg"
                 and CORR_IMPLEMENTATIONS["reg"].__name__ == "CorrBlock1D"):
             return self._iterate_graphed(fmap1, fmap2, net_list, inp_list, iters, flow_init)
         corr_block = CORR_IMPLEMENTATIONS[args.corr_implementation]

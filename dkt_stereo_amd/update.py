@@ -211,6 +211,25 @@ class DispHead(FlowHead):
         super().__init__(input_dim, hidden_dim, output_dim)
 
 
+class _MergedZR:
+    """convz | convr as one Conv2d-like layer.  The activation exponent (conv.calibrate) is kept on the real convz module:
+    it survives a rebuild of this object and is seen by the loop's weight fingerprint (RAFTStereo._weights_fingerprint)."""
+
+    def __init__(self, convz, weight, bias):
+        self._convz = convz
+        self.weight, self.bias = weight, bias
+        self.padding, self.stride, self.dilation, self.groups = convz.padding, convz.stride, convz.dilation, convz.groups
+        self.padding_mode = convz.padding_mode
+
+    @property
+    def dkt_in_exp(self):
+        return getattr(self._convz, "dkt_in_exp", 0)
+
+    @dkt_in_exp.setter
+    def dkt_in_exp(self, e):
+        self._convz.dkt_in_exp = e
+
+
 class ConvGRU(nn.Module):
     """core/update.py:16-32 == meta_arch/igev_stereo/update.py:26-41."""
 
@@ -236,11 +255,8 @@ class ConvGRU(nn.Module):
             hit = cache.get(str(wz.device))
             if hit is None or hit[0] != key:
                 with torch.no_grad():
-                    zr = SimpleNamespace(
-                        weight=torch.cat([wz, wr], dim=0).contiguous(),
-                        bias=torch.cat([self.convz.bias, self.convr.bias], dim=0).contiguous(),
-                        padding=self.convz.padding,
-                        dkt_in_exp=getattr(self.convz, "dkt_in_exp", 0))
+                    zr = _MergedZR(self.convz, torch.cat([wz, wr], dim=0).contiguous(),
+                                   torch.cat([self.convz.bias, self.convr.bias], dim=0).contiguous())
                 hit = cache[str(wz.device)] = (key, zr)
             return hit[1]
 

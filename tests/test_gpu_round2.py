@@ -260,6 +260,32 @@ def test_conv_calibration_leaves_ordinary_layers_alone_and_forward_checks_finite
 
 
 @torch.no_grad()
+def test_conv_calibration_works_with_the_captured_loop():
+    """conv.calibrate() with the default HIP-graph loop: the forward inside the block takes the plain loop (every iteration's
+    ranges recorded, no host sync under capture); the merged z|r layer's exponent lives on convz, survives a rebuild of the
+    merged weights and forces a new capture."""
+    from dkt_stereo_amd import conv
+    model, _ = _raft()
+    assert model.use_hip_graph
+    i1, i2 = _synth.image_pair(0, 1, 64, 128, 12)
+    want = model(G(i1), G(i2), iters=6, test_mode=True)[1]            # captures the loop
+    with conv.calibrate() as rec:
+        model(G(i1), G(i2), iters=6, test_mode=True)
+    assert len(rec) > 30
+    assert "_MergedZR" in {type(l).__name__ for l, _ in rec.values()}
+    assert maxabs(model(G(i1), G(i2), iters=6, test_mode=True)[1], want) <= 1e-4
+    g = model.update_block.gru08
+    fp0 = model._weights_fingerprint()
+    g._merged_zr().dkt_in_exp = -3
+    assert g.convz.dkt_in_exp == -3 and model._weights_fingerprint() != fp0
+    g._zr_cache = None
+    assert conv.in_exp_of(g._merged_zr()) == -3
+    assert maxabs(model(G(i1), G(i2), iters=6, test_mode=True)[1], want) <= 1e-4
+    g._merged_zr().dkt_in_exp = 0
+    assert model._weights_fingerprint() == fp0
+
+
+@torch.no_grad()
 def test_conv_rejects_grouped_and_dilated_layers():
     """Layers the kernel does not implement take the vendor path instead of giving wrong numbers."""
     from dkt_stereo_amd import conv

@@ -120,6 +120,24 @@ def test_merged_zr_cache_is_per_device_and_versioned():
     b = gru._merged_zr()
     assert b is not a and torch.equal(b.bias[8:], gru.convr.bias)
     assert list(gru._zr_cache) == ["cpu"]
+    # the calibrated activation exponent lives on convz: it survives the rebuild of the merged layer
+    b.dkt_in_exp = -3
+    assert gru.convz.dkt_in_exp == -3
+    with torch.no_grad():
+        gru.convz.weight.mul_(2.0)
+    assert gru._merged_zr() is not b and gru._merged_zr().dkt_in_exp == -3
+
+
+def test_few_output_kernel_is_bounded_by_what_it_can_stage():
+    """few_eligible (the 256 -> 2 / 256 -> 1 head layers) stops where conv_direct.hip's launch_few would exceed 160 KB of LDS;
+    wider layers stay on the general kernel instead of raising DKT_E_UNSUPPORTED."""
+    from dkt_stereo_amd import conv
+    mk = lambda cin, cout: torch.nn.Conv2d(cin, cout, 3, padding=1)
+    assert conv.few_eligible(mk(256, 2)) and conv.few_eligible(mk(256, 1)) and conv.few_eligible(mk(256, 4))
+    assert conv.few_eligible(mk(552, 2)) and not conv.few_eligible(mk(553, 2))
+    assert conv.few_eligible(mk(272, 3)) and not conv.few_eligible(mk(280, 4))
+    assert conv.few_eligible(mk(1104, 1)) and not conv.few_eligible(mk(1105, 1))
+    assert not conv.few_eligible(mk(64, 5))
 
 
 @pytest.mark.parametrize("dims,div,mode", [((375, 1242), 32, "kitti"), ((540, 960), 32, "sintel"), ((736, 1248), 32, "kitti"),

@@ -1,5 +1,6 @@
 """Times the 384->256 (cfg 1) and 384->128 (cfg 2) C8S convolutions at 184x312 for the library DKT_LIB_PATH points to."""
 import os, sys, torch
+os.environ.setdefault("DKT_ALLOW_ABLATION", "1")     # this tool times ablation builds (DKT_LIB_PATH)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from c8_check import gtime

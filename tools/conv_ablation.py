@@ -38,4 +38,5 @@ for lib in libs:
     env = dict(os.environ)
     if lib:
         env["DKT_LIB_PATH"] = lib
+        env["DKT_ALLOW_ABLATION"] = "1"          # timing-only builds (the loader refuses them otherwise)
     subprocess.run([sys.executable, "-c", code], env=env)
