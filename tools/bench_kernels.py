@@ -354,10 +354,102 @@ def bench_next():
            flops=2 * 2.0 * H * W * W * 256)
 
 
+@torch.no_grad()
+def bench_c8():
+    """Round 3: the C8S convolution (conv_c8.hip) per layer class of the refinement loop at cfg2 sizes, its producers, the
+    lookup writing C8S, the MFMA group-wise correlation, and the Winograd go/no-go timing proxy."""
+    from dkt_stereo_amd import conv_c8 as c8
+    from dkt_stereo_amd import submodule as sm
+    from dkt_stereo_amd.corr import CorrBlock1D
+    H, W = 184, 312
+    torch.manual_seed(0)
+    mk = lambda cin, cout: torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+
+    def acts(n, h, w, c=128):
+        return [c8.pack(torch.randn(1, c, h, w, device=DEV)) for _ in range(n)]
+
+    fl = lambda cin, cout, h, w: 2.0 * 9 * cin * cout * h * w * 3          # MFMA flops: three split passes
+    # gru08 z|r (tile <4,2,4,4>) and q (<2,4,2,4>) with their gate epilogues
+    a3 = acts(3, H, W)
+    hh = torch.tanh(torch.randn(1, 128, H, W, device=DEV))
+    cz, cr, cq = (torch.randn(1, 128, H, W, device=DEV) for _ in range(3))
+    rh, hc = c8.ActC8(1, 128, H, W, DEV), c8.ActC8(1, 128, H, W, DEV)
+    zr, q = mk(384, 256), mk(384, 128)
+    z = c8.gate_zr(a3, zr, cz, cr, hh, rh_c8=rh, cfg=1)
+    report("conv_c8 gru08 z|r 384->256 + gates (cfg1)", timeit(lambda: c8.gate_zr(a3, zr, cz, cr, hh, rh_c8=rh, cfg=1), n=100), flops=fl(384, 256, H, W))
+    hn = torch.empty_like(hh)
+    report("conv_c8 gru08 q 384->128 + update (cfg2)", timeit(lambda: c8.gate_out(a3, q, cq, z, hh, hn, out_c8=hc, cfg=2), n=100), flops=fl(384, 128, H, W))
+    # Winograd F(2x2,3x3) timing proxy: the same kernel with 16/36 of the K steps (Cin 176 of 384) has the MFMA count of a
+    # Winograd form of the z|r layer with ideal operand reuse -- an upper bound on what the transform could buy
+    a176 = [c8.pack(torch.randn(1, 176, H, W, device=DEV))]
+    zr176 = mk(176, 256)
+    report("  proxy: same layer with 16/36 of the MFMAs (Cin 176)", timeit(lambda: c8.gate_zr(a176, zr176, cz, cr, hh, rh_c8=rh, cfg=1), n=100), flops=fl(176, 256, H, W))
+    # gru16 (92x156), gru32 (46x78): 256 / 384 input channels
+    for name, h, w, nin, cfg in (("gru16", 92, 156, 3, 4), ("gru32", 46, 78, 2, 4)):
+        a = acts(nin, h, w)
+        hs = torch.tanh(torch.randn(1, 128, h, w, device=DEV))
+        g0, g1, g2 = (torch.randn(1, 128, h, w, device=DEV) for _ in range(3))
+        r2, h2 = c8.ActC8(1, 128, h, w, DEV), c8.ActC8(1, 128, h, w, DEV)
+        lz, lq = mk(128 * nin, 256), mk(128 * nin, 128)
+        zz = c8.gate_zr(a, lz, g0, g1, hs, rh_c8=r2, cfg=cfg)
+        report("conv_c8 %s z|r %d->256 (cfg%d)" % (name, 128 * nin, cfg), timeit(lambda: c8.gate_zr(a, lz, g0, g1, hs, rh_c8=r2, cfg=cfg), n=100), flops=fl(128 * nin, 256, h, w))
+        report("conv_c8 %s q %d->128 (cfg%d)" % (name, 128 * nin, cfg), timeit(lambda: c8.gate_out(a, lq, g2, zz, hs, hs, out_c8=h2, cfg=cfg), n=100), flops=fl(128 * nin, 128, h, w))
+    # motion encoder: convc2 | convf2 in one launch, enc.conv with the flow tail; flow head conv1 with the fused projection
+    cor, flo, cf, mf = c8.ActC8(1, 64, H, W, DEV), c8.ActC8(1, 64, H, W, DEV), c8.ActC8(1, 128, H, W, DEV), c8.ActC8(1, 128, H, W, DEV)
+    c8.pack(torch.randn(1, 64, H, W, device=DEV), cor)
+    c8.pack(torch.randn(1, 64, H, W, device=DEV), flo)
+    c2, f2, enc = mk(64, 64), mk(64, 64), mk(128, 126)
+    flow = torch.randn(1, 2, H, W, device=DEV)
+
+    def pair():
+        d0 = c8.desc([cor], c2, relu=True, out_c8=cf, out_c8_ch0=0)
+        d1 = c8.desc([flo], f2, relu=True, out_c8=cf, out_c8_ch0=64)
+        c8.launch_pair(d0, d1, flow, 3)
+    report("conv_c8 convc2 | convf2 64->64 x2, one launch (cfg3)", timeit(pair, n=100), flops=2 * fl(64, 64, H, W))
+    report("conv_c8 encoder.conv 128->126 + flow tail (cfg3)", timeit(lambda: c8.conv2d_c8([cf], enc, relu=True, out_c8=mf, tail=flow, cfg=3), n=100), flops=fl(128, 126, H, W))
+    h1, h2l = mk(128, 256), mk(256, 2)
+    from dkt_stereo_amd.update import _leading_outputs
+    tgt = torch.zeros(1, 1, H, W, device=DEV)
+    report("conv_c8 flow_head.conv1 128->256 + fused conv2 (cfg2) + head_finish", timeit(lambda: c8.head([hc], h1, _leading_outputs(h2l, 1), tgt, cfg=2), n=100), flops=fl(128, 256, H, W))
+    # producers
+    n0, n1 = torch.randn(1, 128, H, W, device=DEV), torch.randn(1, 128, 92, 156, device=DEV)
+    p0, u1 = c8.ActC8(1, 128, 92, 156, DEV), c8.ActC8(1, 128, H, W, DEV)
+    report("pool2x -> C8S 128ch 184x312", timeit(lambda: c8.pool2x_c8(n0, p0), n=200), bytes_=n0.numel() * 4 + 92 * 156 * 128 * 4)
+    report("interp -> C8S 128ch 92x156 -> 184x312", timeit(lambda: c8.interp_c8(n1, u1), n=200), bytes_=n1.numel() * 4 + n0.numel() * 4)
+    st7 = torch.nn.Conv2d(2, 64, 7, padding=3).to(DEV)
+    report("stem7 convf1 2->64 7x7 -> C8S", timeit(lambda: c8.stem7_c8(flow, st7, flo), n=200), bytes_=flow.numel() * 4 + 64 * H * W * 4)
+    # full-resolution encoder layer (opt-in path, DESIGN 3.6)
+    Hf, Wf = 736, 1248
+    xf = c8.pack(torch.randn(1, 64, Hf, Wf, device=DEV))
+    yf = c8.ActC8(1, 64, Hf, Wf, DEV)
+    e64 = mk(64, 64)
+    report("conv_c8 encoder 64->64 @736x1248 -> C8S (cfg3)", timeit(lambda: c8.conv2d_c8([xf], e64, relu=True, out_c8=yf, cfg=3), n=30), flops=fl(64, 64, Hf, Wf))
+    del xf, yf
+    # lookup fused with convc1 writing C8S (block form)
+    c1 = torch.nn.Conv2d(36, 64, 1).to(DEV)
+    for B in (1, 8):
+        f1, f2_ = (torch.randn(B, 256, H, W, device=DEV) for _ in range(2))
+        blk = CorrBlock1D(f1, f2_, num_levels=4, radius=4)
+        coords = torch.zeros(B, 2, H, W, device=DEV)
+        xs = torch.arange(W, device=DEV).float().view(1, 1, W)
+        coords[:, 0] = xs - 20.3 - 3.0 * torch.sin(torch.arange(H, device=DEV).float() / 9.0).view(1, H, 1)
+        dst = c8.ActC8(B, 64, H, W, DEV)
+        report("lookup + convc1 -> C8S B=%d smooth" % B, timeit(lambda: blk.lookup_conv1x1(coords, c1, out_c8=dst), n=200), bytes_=B * H * W * 420)
+        del blk, f1, f2_, dst
+    # group-wise correlation: exact VALU kernel vs the banded MFMA product
+    for name, C, G_, h, w in (("IGEV 96ch G=8", 96, 8, 184, 312), ("GwcNet 320ch G=40", 320, 40, 136, 240)):
+        a, b = (torch.randn(1, C, h, w, device=DEV) for _ in range(2))
+        by = 2 * a.numel() * 4 + G_ * 48 * h * w * 4
+        for mode in ("exact", "mfma"):
+            with sm.gwc_mode(mode):
+                report("gwc_volume %s D=48 [%s]" % (name, mode), timeit(lambda: sm.build_gwc_volume(a, b, 48, G_), n=50), bytes_=by,
+                       flops=2.0 * C * 48 * h * w)
+
+
 def main():
     which = sys.argv[1:] or ["lookup", "build", "gates", "conv", "e2e", "autocast", "volumes"]
     fns = dict(lookup=bench_lookup, build=bench_build, gates=bench_gates, conv=bench_conv, e2e=bench_e2e,
-               autocast=bench_autocast, volumes=bench_volumes, ablate=bench_ablate, next=bench_next)
+               autocast=bench_autocast, volumes=bench_volumes, ablate=bench_ablate, next=bench_next, c8=bench_c8)
     for w in which:
         print("== %s ==" % w, flush=True)
         try:
