@@ -19,6 +19,7 @@ import weakref
 import torch
 
 from . import conv as _conv
+from . import loop_c8
 from .conv import conv2d
 from .update import FUSE_GATES, GPU_GUARD, _side_stream, capture_graph, gru_pair, harness, interp, pool2x, replay_graph
 
@@ -47,6 +48,40 @@ def _plain(update_block, geo_fn, disp, coords, net_list, inp_list, iters):
 
 class _State:
     pass
+
+
+#: the loop on the round-3 convolution (loop_c8.C8LoopIGEV) when the update block and the image size allow it (DKT_C8=0: never)
+USE_C8 = os.environ.get("DKT_C8", "1") != "0"
+
+
+def _iterate_c8(ub, st, iters):
+    """loop_c8.C8LoopIGEV on the state's static buffers: prologue (coarsest GRU of iteration 0), `iters` units -- the first
+    eagerly, one captured, the rest replayed --, the up-sampling mask features from the final hidden state."""
+    lp = getattr(st, "c8", None)
+    d = dict(net=st.net, inp=st.inp, disp=st.disp, coords=st.coords, geo_fn=st.geo_fn)
+    if lp is None:
+        lp = st.c8 = loop_c8.C8LoopIGEV(ub, d)
+    with harness(inplace_state=True, side_stream=False):
+        lp.prologue(d)
+        keep = None
+        for k in range(iters):
+            if k == iters - 1:
+                # every unit also advances the coarsest GRU for the NEXT iteration (it rides in the finest GRU's launches);
+                # the caller gets the state the reference's loop ends with
+                keep = st.net[2].clone()
+            if lp.graph is None:
+                lp.unit(d)                       # eager once: packs weights, sizes the allocator
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with capture_graph(g):
+                    lp.unit(d)
+                lp.graph = g                     # (capturing records, it does not execute)
+            else:
+                replay_graph(lp.graph)
+        if keep is not None:
+            st.net[2].copy_(keep)
+        mask = conv2d(st.net[0], ub.mask_feat_4[0], relu=True)
+    return st.disp.clone(), mask, [t.clone() for t in st.net]
 
 
 def _body(ub, st, need_mask, last):
@@ -184,7 +219,7 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
     if not pipelined:
         return _plain(update_block, geo_fn, init_disp, coords, list(net_list), inp_list, iters)
     key = (init_disp.device, tuple(init_disp.shape), tuple(geo_fn._shape), geo_fn._w2, geo_fn.num_levels,
-           geo_fn.radius, _fingerprint(update_block), ROTATE, PAIR_GRUS)
+           geo_fn.radius, _fingerprint(update_block), ROTATE, PAIR_GRUS, USE_C8)
     st = cache.get("state") if cache is not None else None
     if st is None or st.key != key or st.ub() is not update_block:
         st = _State()
@@ -217,6 +252,8 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
             for dst, src in zip(ds, ss):
                 dst.copy_(src)
     ub = update_block
+    if USE_C8 and loop_c8.eligible_igev(ub, st.net[0].shape):
+        return _iterate_c8(ub, st, iters)
     if ROTATE and PAIR_GRUS:
         mask = _iterate_rotated(ub, st, iters)
         return st.disp.clone(), mask, [t.clone() for t in st.net]

@@ -31,24 +31,35 @@ MIN_PIXELS = int(os.environ.get("DKT_C8_MIN_PIXELS", "24000"))
 
 
 def eligible(model, shape=None):
-    a = model.args
+    """RAFT-Stereo's update block (core/update.py:97-138) on this loop."""
+    return _eligible_block(model.update_block, shape, 126)
+
+
+def eligible_igev(ub, shape=None):
+    """IGEV's update block (meta_arch/igev_stereo/update.py:94-142: gru04 / gru08 / gru16, 127-channel motion encoder,
+    one-output disparity head) on this loop."""
+    return (_eligible_block(ub, shape, 127) and all(hasattr(ub, n) for n in ("gru04", "gru08", "gru16", "disp_head"))
+            and ub.disp_head.conv2.weight.shape[0] == 1)
+
+
+def _eligible_block(ub, shape, enc_out):
+    a = ub.args
     if shape is not None and shape[2] * shape[3] < MIN_PIXELS:
         return False
-    ub = model.update_block
-    if a.n_gru_layers != 3 or a.slow_fast_gru or _conv.get_backend() != "f16x3":
+    if a.n_gru_layers != 3 or getattr(a, "slow_fast_gru", False) or _conv.get_backend() != "f16x3":
         return False
     if any(getattr(m, "dkt_in_exp", 0) for m in ub.modules()):
         return False                      # calibrated activation exponents: the round-2 kernels handle those
     hd = list(a.hidden_dims)
-    return hd == [128, 128, 128] and ub.encoder.conv.weight.shape[0] == 126
+    return hd == [128, 128, 128] and ub.encoder.conv.weight.shape[0] == enc_out
 
 
 class C8Loop:
     """Buffers and the captured unit for one (shape, weights) state of RAFTStereo._iterate_graphed."""
 
     def __init__(self, model, st):
-        self.model = model
-        ub = model.update_block
+        self.ub = ub = getattr(model, "update_block", model)
+        self.grus = self._gru_modules(ub)                # finest, middle, coarsest
         n0, n1, n2 = st["net"]
         dev = n0.device
         B = n0.shape[0]
@@ -63,6 +74,10 @@ class C8Loop:
         self.hidden = torch.empty((B, 256, n0.shape[2], n0.shape[3]), device=dev, dtype=torch.float32)
         self.graph = None
 
+    @staticmethod
+    def _gru_modules(ub):
+        return ub.gru08, ub.gru16, ub.gru32
+
     # ---- pieces -------------------------------------------------------------------------------------------------
     def _gru(self, lvl, gru, st, xs, cfg_zr, cfg_q):
         h = st["net"][lvl]
@@ -72,10 +87,10 @@ class C8Loop:
 
     def _gru_pair(self, st):
         """gru08 of this iteration and gru32 of the next one in two shared launches."""
-        ub = self.model.update_block
+        fine, _, coarse = self.grus
         ds = []
         zs = []
-        for lvl, gru, xs in ((0, ub.gru08, [self.mf, self.up1]), (2, ub.gru32, [self.pool1])):
+        for lvl, gru, xs in ((0, fine, [self.mf, self.up1]), (2, coarse, [self.pool1])):
             h = st["net"][lvl]
             cz, cr, _ = st["inp"][lvl]
             z = torch.empty_like(h)
@@ -83,14 +98,14 @@ class C8Loop:
             ds.append(c8.desc([self.hc8[lvl], *xs], gru._merged_zr(), out=z, epilogue=1, e0=cz, e1=cr, h=h, out2_c8=self.rh[lvl]))
         c8.launch_pair(ds[0], ds[1], zs[0], _CFG["zr08"])
         ds = []
-        for (lvl, gru, xs), z in zip(((0, ub.gru08, [self.mf, self.up1]), (2, ub.gru32, [self.pool1])), zs):
+        for (lvl, gru, xs), z in zip(((0, fine, [self.mf, self.up1]), (2, coarse, [self.pool1])), zs):
             h = st["net"][lvl]
             cq = st["inp"][lvl][2]
             ds.append(c8.desc([self.rh[lvl], *xs], gru.convq, out=h, out_c8=self.hc8[lvl], epilogue=2, e0=cq, e1=z, h=h))
         c8.launch_pair(ds[0], ds[1], zs[0], _CFG["q08"])
 
     def _motion(self, st):
-        enc = self.model.update_block.encoder
+        enc = self.ub.encoder
         if st["corr"].lookup_conv1x1(st["coords1"], enc.convc1, out_c8=self.cor) is None:
             c8.pack(st["corr"].lookup_conv1x1(st["coords1"], enc.convc1), self.cor)
         c8.stem7_c8(st["flow"], enc.convf1, self.flo)
@@ -100,7 +115,7 @@ class C8Loop:
         c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["flow"], cfg=_CFG["enc"])
 
     def _head(self, st):
-        fh = self.model.update_block.flow_head
+        fh = self.ub.flow_head
         if FUSE_HEAD:
             # conv2 (x output only: raft_stereo.py:165) from per-tap projections made in conv1's epilogue
             c8.head([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), st["coords1"][:, :1],
@@ -114,7 +129,7 @@ class C8Loop:
         n0, n1, n2 = st["net"]
         c8.pool2x_c8(n0, self.pool0)
         c8.interp_c8(n2, self.up2)
-        self._gru(1, self.model.update_block.gru16, st, [self.pool0, self.up2], _CFG["zr16"], _CFG["q16"])
+        self._gru(1, self.grus[1], st, [self.pool0, self.up2], _CFG["zr16"], _CFG["q16"])
         c8.interp_c8(n1, self.up1)
         c8.pool2x_c8(n1, self.pool1)
 
@@ -130,4 +145,30 @@ class C8Loop:
         for lvl, n in enumerate(st["net"]):
             c8.pack(n, self.hc8[lvl])
         c8.pool2x_c8(n1, self.pool1)
-        self._gru(2, self.model.update_block.gru32, st, [self.pool1], 4, 4)
+        self._gru(2, self.grus[2], st, [self.pool1], 4, 4)
+
+
+class C8LoopIGEV(C8Loop):
+    """The IGEV refinement loop (meta_arch/igev_stereo/igev_stereo.py:199-210 with the update block of
+    igev_stereo/update.py:94-142) on the same kernels: gru04 / gru08 / gru16 at 1/4, 1/8, 1/16, the geometry-encoding
+    lookup (geometry.py:29-69) in front of the 162 -> 64 1x1 layer, a 1-channel disparity stem, the 127 + 1 channel motion
+    features and the one-output disparity head whose result is added to the running disparity in dkt_head_finish.
+    ``st``: dict(net, inp, disp, coords, geo_fn)."""
+
+    @staticmethod
+    def _gru_modules(ub):
+        return ub.gru04, ub.gru08, ub.gru16
+
+    def _motion(self, st):
+        enc = self.ub.encoder
+        geo = st["geo_fn"](st["disp"], st["coords"])
+        c8.pack(_conv.conv2d(geo, enc.convc1, relu=True), self.cor)
+        c8.stem7_c8(st["disp"], enc.convd1, self.flo)
+        d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
+        d1 = c8.desc([self.flo], enc.convd2, relu=True, out_c8=self.cf, out_c8_ch0=64)
+        c8.launch_pair(d0, d1, st["disp"], _CFG["c2"])
+        c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["disp"], cfg=_CFG["enc"])
+
+    def _head(self, st):
+        dh = self.ub.disp_head
+        c8.head([self.hc8[0]], dh.conv1, dh.conv2, st["disp"], cfg=_CFG["head"])      # disp += delta (igev_stereo.py:209)

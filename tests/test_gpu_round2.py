@@ -80,8 +80,13 @@ def test_igev_loop_fixtures(name, golden):
     assert dd <= 1e-3 and dm <= 1e-3
     got_d, got_m, _ = igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, c["iters"], cache={})
     if c["n"] == 3 and not c["slow_fast"]:
-        # graph + pipelined GRUs: same arithmetic, same order of updates
-        assert torch.equal(got_d, want_d) and torch.equal(got_m, want_m)
+        from dkt_stereo_amd import igev_loop, loop_c8
+        if igev_loop.USE_C8 and loop_c8.eligible_igev(blk, net[0].shape):
+            # round-3 kernels (loop_c8.C8LoopIGEV): the same split-fp16 arithmetic in another accumulation order
+            assert maxabs(got_d, want_d) <= 2e-4 and maxabs(got_m, want_m) <= 2e-4
+        else:
+            # graph + pipelined GRUs: same arithmetic, same order of updates
+            assert torch.equal(got_d, want_d) and torch.equal(got_m, want_m)
     assert maxabs(got_d, g[name + "/disp"]) <= 1e-3
     assert maxabs(got_m[:, :, ::st, ::st], g[name + "/mask"]) <= 1e-3
 

@@ -314,3 +314,29 @@ def test_encoder_layer1_on_c8_matches_round2_path(monkeypatch):
     g0 = m.fnet._trunk(x2)
     monkeypatch.setattr(ex, "C8_ENCODER", True)
     assert _rel(m.fnet._trunk(x2), g0) <= 2e-5
+
+
+@torch.no_grad()
+def test_igev_c8_loop_matches_round2_loop_and_fixture(golden, monkeypatch):
+    """IGEV's refinement loop on the C8S kernels (loop_c8.C8LoopIGEV) at the cfg3 shapes, 32 iterations: against the round-2
+    loop (same arithmetic, another accumulation order), the reference fixture (<= 1e-3), and itself replayed with a new
+    volume of the same shapes."""
+    from test_gpu_round2 import _igev_setup
+    from dkt_stereo_amd import igev_loop, loop_c8
+    c = _cases.IGEV_LOOP_CASES["kitti"]
+    blk, geo_fn, d0, coords, net, inp, _ = _igev_setup(c)
+    assert loop_c8.eligible_igev(blk, net[0].shape)
+    g = golden("igev_loop")
+    st = int(g["kitti/mask_stride"])
+    monkeypatch.setattr(igev_loop, "USE_C8", False)
+    r2_d, r2_m, r2_n = igev_loop.igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, c["iters"], cache={})
+    monkeypatch.setattr(igev_loop, "USE_C8", True)
+    cache = {}
+    d, m, n = igev_loop.igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, c["iters"], cache=cache)
+    assert getattr(cache["state"], "c8", None) is not None
+    e_d, e_m, e_n = maxabs(d, r2_d), maxabs(m, r2_m), max(maxabs(a, b) for a, b in zip(n, r2_n))
+    print("igev c8 loop vs round-2 loop: disp %.2e mask %.2e net %.2e; vs fixture %.2e" % (e_d, e_m, e_n, maxabs(d, g["kitti/disp"])))
+    assert e_d <= 2e-4 and e_m <= 2e-4 and e_n <= 2e-4
+    assert maxabs(d, g["kitti/disp"]) <= 1e-3 and maxabs(m[:, :, ::st, ::st], g["kitti/mask"]) <= 1e-3
+    d2, m2, _ = igev_loop.igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, c["iters"], cache=cache)
+    assert torch.equal(d2, d) and torch.equal(m2, m)            # second call: all units replayed from the captured graph
