@@ -20,9 +20,12 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 launch stream (frac = frac_algorithmic; mfma_issue_frac counts the 3 fp16 MFMA
                 passes per product); roofline_lookup: the corr-lookup kernel (HBM-bound, the
                 kernel BASELINE.json's north_star sets the 60 % target for) -- since round 2 it
-                is fused with the 1x1 layer that consumes it.  `traffic`: 2 x FETCH_SIZE +
-                WRITE_SIZE from profiles/r02_hbm_traffic.txt (separate rocprofv3 --pmc passes
-                of the same kernels and shapes, calibrated on known-traffic streams)
+                is fused with the 1x1 layer that consumes it; stand-alone launch time, plus
+                `in_pipeline_*`: the same kernel as the loop runs it (rocprofv3 trace of this
+                command, profiles/r03_pair_breakdown.txt).  `traffic`: 2 x FETCH_SIZE +
+                WRITE_SIZE from profiles/r03_hbm_traffic.txt (separate rocprofv3 --pmc passes
+                of the same kernels and shapes, calibrated on known-traffic streams; the
+                round-2 kernels' figures are in profiles/r02_hbm_traffic.txt)
   cpu_baseline  oracle/torch_oracle.py (pure-PyTorch CPU port of the reference,
                 pinned to it by tests/golden) timed on this host, bounded sample
 """
@@ -350,7 +353,12 @@ def main():
     # rocprofv3 runs of the same kernels on the same shapes); None when the file is absent
     traffic = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")) else "r02_hbm_traffic.json")) as f:
+        # round 3's passes measured the C8S kernels (conv_c8_kernel, corr_feat64_kernel); the round-2 kernels' figures
+        # (other conv backends, small images) are in the round-2 file
+        name = "r03_hbm_traffic.json" if c8_used else "r02_hbm_traffic.json"
+        if not os.path.exists(os.path.join(ROOT, "profiles", name)):
+            name = "r02_hbm_traffic.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             traffic = json.load(f)
     except (OSError, ValueError):
         pass
@@ -401,7 +409,7 @@ def main():
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
         # the kernel BASELINE.json's north_star sets the HBM target for
-        "roofline_lookup": {"kernel": ("corr_feat16_kernel<4,4> (dkt_corr1d_lookup_conv1x1%s): pyramid lookup fused with "
+        "roofline_lookup": {"kernel": ("corr_feat64_kernel<4> (dkt_corr1d_lookup_conv1x1%s): pyramid lookup fused with "
                                        "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA" % ("_c8, C8S output" if c8_used else "")) if fused_lookup
                             else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
