@@ -452,7 +452,9 @@ class RAFTStereo(nn.Module):
                 lp.graph = g                 # (capturing does not execute: still one unit done)
             for _ in range(iters - done):
                 replay_graph(lp.graph)
-            return .25 * conv2d(conv2d(st["net"][0], ub.mask[0], relu=True), ub.mask[2])
+            # up-sampling mask head (core/update.py:107-110, :136) from the final hidden state: its 3x3 layer reads the C8S twin
+            from . import conv_c8
+            return .25 * conv2d(conv_c8.conv2d_c8([lp.hc8[0]], ub.mask[0], relu=True, cfg=1), ub.mask[2])
 
     def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init):
         """Same arithmetic as the eager loop; iterations 2..iters-1 are replays of one

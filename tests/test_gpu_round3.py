@@ -340,3 +340,22 @@ def test_igev_c8_loop_matches_round2_loop_and_fixture(golden, monkeypatch):
     assert maxabs(d, g["kitti/disp"]) <= 1e-3 and maxabs(m[:, :, ::st, ::st], g["kitti/mask"]) <= 1e-3
     d2, m2, _ = igev_loop.igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, c["iters"], cache=cache)
     assert torch.equal(d2, d) and torch.equal(m2, m)            # second call: all units replayed from the captured graph
+
+
+def test_few_output_kernel_is_exact_beside_lds_holders_without_the_exclusive_claim():
+    """DESIGN 3.4 / ADVICE r02: tools/stress_lds_dma.py with DKT_FEW_LDS_EXACT=1 -- the few-output head kernel requests only
+    the LDS it needs, so blocks of the 1/16-resolution GRU convolution on a second stream share its CUs (the situation that
+    gave 1000 wrong launches of 1200 with the packed-FMA build).  The scalar-FMA build (-fno-slp-vectorize) must be exact in
+    every launch, and so must the co-resident convolution."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DKT_FEW_LDS_EXACT="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_lds_dma.py")], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("exact-LDS=1")]
+    assert len(lines) == 2, res.stdout[-2000:]
+    for ln in lines:
+        assert "few-kernel results wrong 0/1200" in ln and "co-resident conv results wrong 0/600" in ln, ln
