@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void corr_feat16_kernel(CorrFeatArgs a) {
 template <int R>
 __global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
     constexpr int K = 2 * R + 1;
-    constexpr int PITCH = 65;
+    constexpr int PITCH = 65;          // (80 -- k rows 16 banks apart -- measured the same: LDS is not the limiter)
     __shared__ float vs[4 * K * PITCH];
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -423,6 +423,21 @@ __global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
     const long hrow = blockIdx.x / nseg;
     const int seg0 = (int)(blockIdx.x - hrow * nseg) * 64;
     const int b = blockIdx.y;
+    // phase 2's weight fragments (wave m = g: channels 16m .. 16m+15, k = 4 step + q) are fetched FIRST: left inside the
+    // k loop each of them was an L2 round trip on the critical path behind the barrier (the 36 x 64 matrix is shared by
+    // every block, but a block touches it once) -- issued here their latency hides under the sampling phase
+    constexpr int NS = (4 * K) / 4;           // k steps of 4 (4 K is a multiple of 4)
+    float Aw[NS];
+    {
+        const int j = lane & 15, q = lane >> 4;
+        const int co = 16 * g + j;
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const int kk = 4 * sidx + q;
+            const float wv = a.w[(long)kk * a.Cout + (co < a.Cout ? co : 0)];
+            Aw[sidx] = co < a.Cout ? wv : 0.0f;
+        }
+    }
     {
         const int w1 = seg0 + lane;
         const bool live = w1 < a.W1;
@@ -488,15 +503,11 @@ __global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
     f32x4_ acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_{0.f, 0.f, 0.f, 0.f};
-    constexpr int NS = (4 * K) / 4;           // k steps of 4 (4 K is a multiple of 4)
 #pragma unroll
     for (int sidx = 0; sidx < NS; ++sidx) {
         const int kk = 4 * sidx + q;
-        const int co = 16 * m + j;
-        const float wv = a.w[(long)kk * a.Cout + (co < a.Cout ? co : 0)];
-        const float A = co < a.Cout ? wv : 0.0f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, vs[kk * PITCH + 16 * t + j], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[sidx], vs[kk * PITCH + 16 * t + j], acc[t], 0, 0, 0);
     }
     float bv[4];
 #pragma unroll

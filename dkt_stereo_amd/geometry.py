@@ -17,7 +17,7 @@ dkt_corr1d_pool_bwd; ``disp`` must be detached, as the reference's loop does.
 import torch
 
 from . import _ffi
-from .corr import _BuildFn, _build_pyramid
+from .corr import _BuildFn, _WT_LOCK, _build_pyramid
 
 
 def _pool_geo(geo_volume, num_levels, out=None):
@@ -168,6 +168,50 @@ class Combined_Geo_Encoding_Volume:
                                     "disp as the reference's loop does (igev_stereo.py:200)")
             return _GeoLookupFn.apply(disp, coords, self, *levels)
         return self._lookup(disp, coords, self.geo_volume_pyramid, self.init_corr_pyramid)
+
+    def lookup_conv1x1(self, disp, coords, layer, relu=True, tap=False, out_c8=None, out_c8_ch0=0):
+        """relu(layer(self(disp, coords))) for a 1x1 ``layer`` with <= 64 outputs (the motion encoder's convc1,
+        igev_stereo/update.py:78,86) without ever writing the L*(2r+1)*(C+1)-channel lookup (dkt_geo_lookup_conv1x1).
+        Returns None when the fused kernel does not cover the configuration (anything but 2 levels, 8 geometry channels,
+        radius 4; autograd involved): run the two steps separately then.  ``out_c8``: write the C8S operand of the next
+        convolution (conv_c8) instead of fp32 NCHW.  tap=True additionally returns the sampled values (bit-identical to
+        ``self(disp, coords)``)."""
+        w = layer.weight
+        b, c, d, h, wd = self._shape
+        K = 2 * self.radius + 1
+        levels = self.geo_volume_pyramid + self.init_corr_pyramid
+        if (w.dim() != 4 or tuple(w.shape[2:]) != (1, 1) or w.shape[0] > 64 or w.shape[1] != self.num_levels * K * (c + 1)
+                or self.num_levels != 2 or c != 8 or self.radius != 4 or (d >> 1) == 0 or (self._w2 >> 1) == 0
+                or getattr(layer, "groups", 1) != 1 or tuple(getattr(layer, "stride", (1, 1))) != (1, 1)
+                or (torch.is_grad_enabled() and (w.requires_grad or disp.requires_grad or any(t.requires_grad for t in levels)))):
+            return None
+        _ffi.require_gpu(disp, coords)
+        if disp.dtype != torch.float32 or disp.stride(3) != 1 or disp.stride(2) != wd:
+            disp = disp.float().contiguous()
+        coords = coords.float().contiguous()
+        cout = w.shape[0]
+        key = (w.data_ptr(), w._version)
+        with _WT_LOCK:
+            cache = layer.__dict__.setdefault("_dkt_wt", {})
+            hit = cache.get(str(w.device))
+            if hit is None or hit[0] != key:
+                hit = cache[str(w.device)] = (key, w.detach().reshape(cout, -1).t().float().contiguous())
+        wm = hit[1]
+        bias = layer.bias
+        out = None if out_c8 is not None else torch.empty((b, cout, h, wd), device=disp.device, dtype=torch.float32)
+        tp = torch.empty((b, w.shape[1], h, wd), device=disp.device, dtype=torch.float32) if tap else None
+        rc = _ffi.lib().dkt_geo_lookup_conv1x1(
+            _ffi.ptr_array(self.geo_volume_pyramid), _ffi.ptr_array(self.init_corr_pyramid),
+            disp.data_ptr(), disp.stride(0), coords.data_ptr(), wm.data_ptr(),
+            None if bias is None else bias.detach().data_ptr(),
+            None if out is None else out.data_ptr(), 0 if out is None else out.stride(0),
+            None if out_c8 is None else out_c8.data_ptr(), 0 if out_c8 is None else out_c8.bstride_bytes, out_c8_ch0,
+            1.0 if out_c8 is None else out_c8.scale, None if tp is None else tp.data_ptr(), 0 if tp is None else tp.stride(0),
+            b, c, d, h, wd, self._w2, self.num_levels, self.radius, cout, int(bool(relu)),
+            _ffi.device_of(disp), _ffi.stream_of(disp))
+        _ffi.check(rc, "dkt_geo_lookup_conv1x1")
+        res = out if out_c8 is None else out_c8
+        return (res, tp) if tap else res
 
     @staticmethod
     def corr(fmap1, fmap2):

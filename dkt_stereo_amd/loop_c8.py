@@ -161,8 +161,10 @@ class C8LoopIGEV(C8Loop):
 
     def _motion(self, st):
         enc = self.ub.encoder
-        geo = st["geo_fn"](st["disp"], st["coords"])
-        c8.pack(_conv.conv2d(geo, enc.convc1, relu=True), self.cor)
+        # geometry lookup + convc1 + ReLU in one kernel, straight into the C8S operand (dkt_geo_lookup_conv1x1)
+        if st["geo_fn"].lookup_conv1x1(st["disp"], st["coords"], enc.convc1, out_c8=self.cor) is None:
+            geo = st["geo_fn"](st["disp"], st["coords"])
+            c8.pack(_conv.conv2d(geo, enc.convc1, relu=True), self.cor)
         c8.stem7_c8(st["disp"], enc.convd1, self.flo)
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convd2, relu=True, out_c8=self.cf, out_c8_ch0=64)

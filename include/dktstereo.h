@@ -500,6 +500,19 @@ int dkt_instance_norm_join_c8(const float *c, const float *c_mean_invstd, int c_
                               const float *a, const float *a_mean_invstd, int a_relu,
                               float *y, void *dst, long dst_bstride_bytes, int ch0, float act_scale,
                               int B, int C, int H, int W, int device, void *stream);
+/* IGEV's geometry-encoding lookup (dkt_geo_lookup; meta_arch/igev_stereo/geometry.py:29-69) fused with the motion
+ * encoder's 1x1 layer (convc1, igev_stereo/update.py:78,86): out[b, co] = [relu](bias[co] + sum_k weight_t[k][co] *
+ * lookup[b, k]) -- the L*(2r+1)*(C+1)-channel lookup is never written.  weight_t: (L*(2r+1)*(C+1), Cout) k-major, k in the
+ * lookup's channel order.  disp: (B,1,H,W) with batch stride disp_bstride (floats); coords: (B,H,W) dense.  Destinations:
+ * out (fp32 NCHW) and / or out_c8 (C8S, first channel out_c8_ch0); tap (optional) receives the lookup itself, bit-identical
+ * to dkt_geo_lookup.  Supported: L = 2, C = 8, r = 4, Cout <= 64; otherwise DKT_E_UNSUPPORTED. */
+int dkt_geo_lookup_conv1x1(const float *const *geo_pyr, const float *const *init_pyr,
+                           const float *disp, long disp_bstride, const float *coords,
+                           const float *weight_t, const float *bias,
+                           float *out, long out_bstride, void *out_c8, long out_c8_bstride_bytes, int out_c8_ch0,
+                           float act_scale, float *tap, long tap_bstride,
+                           int B, int C, int D, int H, int W, int W2, int L, int r, int Cout, int relu,
+                           int device, void *stream);
 int dkt_corr1d_lookup_conv1x1_c8(const float *const *skew, const float *coords_x, long coords_bstride,
                                  const float *weight, const float *bias, void *out_c8, long out_c8_bstride_bytes,
                                  int out_c8_ch0, float act_scale, int B, int H, int W1, int W2, int L, int r, int Cout,

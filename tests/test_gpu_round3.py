@@ -359,3 +359,46 @@ def test_few_output_kernel_is_exact_beside_lds_holders_without_the_exclusive_cla
     assert len(lines) == 2, res.stdout[-2000:]
     for ln in lines:
         assert "few-kernel results wrong 0/1200" in ln and "co-resident conv results wrong 0/600" in ln, ln
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [(1, 40, 72, 48), (2, 23, 100, 32), (1, 184, 312, 48)])
+def test_geo_lookup_fused_with_convc1(shape):
+    """IGEV's geometry lookup fused with the motion encoder's 1x1 layer (dkt_geo_lookup_conv1x1): the tap output is the plain
+    lookup bit for bit, the 64 channels match an fp64 evaluation of the 1x1 layer on it, the C8S output is the split of the
+    fp32 one; ragged widths, batch 2, smooth and random disparities."""
+    from dkt_stereo_amd.geometry import Combined_Geo_Encoding_Volume
+    c8 = _c8()
+    B, H, W, D = shape
+    m1, m2 = G(_synth.normal((B, 24, H, W), 11, "m1")), G(_synth.normal((B, 24, H, W), 11, "m2"))
+    geo = G(_synth.normal((B, 8, D, H, W), 12, "geo"))
+    fn = Combined_Geo_Encoding_Volume(m1, m2, geo, radius=4, num_levels=2)
+    coords = torch.arange(W, device=DEV).float().view(1, 1, W, 1).repeat(B, H, 1, 1)
+    layer = torch.nn.Conv2d(162, 64, 1).to(DEV)
+    torch.manual_seed(6)
+    xs = torch.arange(W, device=DEV).float().view(1, 1, 1, W)
+    for kind in ("smooth", "random", "edge"):
+        if kind == "smooth":
+            disp = (3.0 + (D - 8.0) * xs / W + 0.3 * torch.rand(B, 1, H, W, device=DEV)).contiguous()
+        elif kind == "random":
+            disp = torch.rand(B, 1, H, W, device=DEV) * (D + 10) - 5
+        else:
+            disp = torch.full((B, 1, H, W), -3.5, device=DEV)
+            disp[:, :, ::2] = D + 2.25
+        want_tap = fn(disp, coords)
+        out, tap = fn.lookup_conv1x1(disp, coords, layer, relu=True, tap=True)
+        assert torch.equal(tap, want_tap), kind
+        ref = F.conv2d(want_tap.double(), layer.weight.double(), layer.bias.double()).clamp_min(0)
+        assert _rel(out, ref) <= 2e-6, (kind, _rel(out, ref))
+        dst = c8.ActC8(B, 64, H, W, DEV)
+        assert fn.lookup_conv1x1(disp, coords, layer, relu=True, out_c8=dst) is dst
+        assert torch.equal(c8.unpack(dst), c8.unpack(c8.pack(out))), kind
+        t = dst.t.clone()
+        t[:, :, :, 1:H + 1, 1:W + 1, :] = 0
+        assert float(t.abs().max()) == 0.0
+        # a disparity view with a batch stride (the loop keeps it in the tail of a wider buffer)
+        wide = torch.zeros(B, 3, H, W, device=DEV)
+        wide[:, 2:] = disp
+        assert torch.equal(fn.lookup_conv1x1(wide[:, 2:], coords, layer, relu=True), out)
+    # configurations outside the fused form are declined (the caller runs the two steps)
+    assert fn.lookup_conv1x1(disp, coords, torch.nn.Conv2d(162, 96, 1).to(DEV)) is None

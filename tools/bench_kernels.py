@@ -302,6 +302,14 @@ def bench_volumes():
     xs = torch.arange(312, device=DEV).float().view(1, 1, 1, 312)
     smooth = (8.0 + 24.0 * xs / 312 + 0.3 * torch.rand(1, 1, 184, 312, device=DEV)).contiguous()
     report("geo_lookup IGEV cfg3 (smooth disparity)", timeit(lambda: fn(smooth, coords), n=50), bytes_=184 * 312 * 1376)
+    # fused with the motion encoder's 1x1 layer (162 -> 64): algorithmic bytes = the pyramids' windows + disp + coords + output
+    from dkt_stereo_amd import conv_c8 as c8
+    c1 = torch.nn.Conv2d(162, 64, 1).to(DEV)
+    alg = 184 * 312 * (162 * 2 * 4 * 10 // 9 // 2 + 8 + 256)
+    dst = c8.ActC8(1, 64, 184, 312, DEV)
+    report("geo_lookup + convc1 fused -> C8S (smooth)", timeit(lambda: fn.lookup_conv1x1(smooth, coords, c1, out_c8=dst), n=50), bytes_=184 * 312 * (728 + 256))
+    report("geo_lookup + convc1 fused -> fp32 (smooth)", timeit(lambda: fn.lookup_conv1x1(smooth, coords, c1), n=50), bytes_=184 * 312 * (728 + 256))
+    report("geo_lookup + convc1 fused -> C8S (random)", timeit(lambda: fn.lookup_conv1x1(disp, coords, c1, out_c8=dst), n=50), bytes_=184 * 312 * (728 + 256))
 
 
 def bench_next():
