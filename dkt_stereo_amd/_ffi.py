@@ -56,6 +56,7 @@ SIGNATURES = {
     "dkt_conv2d_stem7_c8": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_stem7_dual": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_instance_norm_join_c8": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _vp],
+    "dkt_normalize_pair": [_vp, _l, _vp, _l, _vp, _i, _l, _i, _vp],
     "dkt_geo_lookup_conv1x1": [_pp, _pp, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _i, _f, _vp, _l,
                                _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_corr1d_lookup_conv1x1_c8": [_pp, _vp, _l, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

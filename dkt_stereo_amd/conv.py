@@ -550,3 +550,64 @@ def conv2d_gate_out(x, q_layer, cq, z, h, out=None):
                                              op.passes, _ffi.device_of(out), _ffi.stream_of(out))
     _ffi.check(rc, "dkt_conv2d_f16s_gate_out")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Autograd of the stride-1 "same" convolution (training through the update operator, tools/ft_dkt.py:223-242): forward and
+# the input gradient run on this library's convolution kernels (the input gradient of a stride-1 same convolution is the
+# same convolution with the weights transposed over (Cout, Cin) and rotated by 180 degrees), the weight gradient -- a
+# reduction over all pixels, a different loop nest -- on the vendor library (torch.nn.grad.conv2d_weight), the bias gradient
+# is a sum.
+# ---------------------------------------------------------------------------------------------------------------------
+class _LayerShim:
+    """Duck-types the `layer` argument of conv2d() for detached tensors inside the autograd function."""
+
+    def __init__(self, weight, bias, padding):
+        self.weight, self.bias, self.padding = weight, bias, padding
+        self.stride, self.dilation, self.groups, self.padding_mode = (1, 1), (1, 1), 1, "zeros"
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        kh, kw = weight.shape[2:]
+        pad = (kh // 2, kw // 2)
+        with torch.no_grad():
+            y = conv2d(x.detach(), _LayerShim(weight.detach(), None if bias is None else bias.detach(), pad), relu=relu)
+        ctx.relu, ctx.pad, ctx.has_bias = bool(relu), pad, bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        if ctx.relu:
+            gy = gy * (y > 0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            with torch.no_grad():
+                wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()
+                gx = conv2d(gy, _LayerShim(wt, None, ctx.pad))
+        if ctx.needs_input_grad[1]:
+            gw = torch.nn.grad.conv2d_weight(x.detach(), weight.shape, gy, stride=1, padding=ctx.pad)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0, 2, 3))
+        return gx, gw, gb, None
+
+
+def conv2d_autograd(x, layer, relu=False):
+    """[relu](conv(x) + bias) for a stride-1 "same" layer (odd square kernel, no groups / dilation) as an autograd node:
+    `x` a tensor or a list of tensors (the reference's torch.cat operands).  Other layers run as plain torch."""
+    if isinstance(x, (list, tuple)):
+        x = x[0] if len(x) == 1 else torch.cat(list(x), dim=1)
+    w = layer.weight
+    kh, kw = w.shape[2:]
+    pad = layer.padding
+    pad = (pad, pad) if isinstance(pad, int) else tuple(pad)
+    if (not x.is_cuda or x.dtype != torch.float32 or kh != kw or kh % 2 == 0 or pad != (kh // 2, kw // 2)
+            or _stride_of(layer) != (1, 1) or not _plain_conv(layer)):
+        y = F.conv2d(x, w, layer.bias, stride=_stride_of(layer), padding=layer.padding,
+                     dilation=getattr(layer, "dilation", 1), groups=getattr(layer, "groups", 1))
+        return F.relu(y) if relu else y
+    return _Conv2dFn.apply(x.contiguous(), w, layer.bias, relu)

@@ -9,8 +9,10 @@ path can run, be timed and be parity-checked on a machine where the reference
 is not present.
 
 ``forward(image1, image2, iters, flow_init, test_mode)`` follows the reference
-call convention (tools/evaluate_stereo.py:129).  Only ``test_mode=True`` is
-implemented: the HIP operators are inference-only.
+call convention (tools/evaluate_stereo.py:129).  ``test_mode=True`` is the inference
+hot path (captured loop, fused epilogues); ``test_mode=False`` with autograd enabled
+is the training forward (tools/ft_dkt.py:223): every iteration's prediction, the
+correlation block and the update operator as autograd nodes on this library's kernels.
 """
 import os
 import threading
@@ -155,10 +157,29 @@ class RAFTStereo(nn.Module):
         replay_graph(st["graph"])
         return st["out"]
 
-    def _encode(self, image1, image2):
+    @staticmethod
+    def _normalized_pair(image1, image2):
+        """(image1', image2', both) with x' = 2 * (x / 255) - 1 (raft_stereo.py:91-92) and both = cat([image1', image2']) --
+        one kernel (dkt_normalize_pair) writing the concatenated batch the feature encoder consumes; the halves are views."""
+        if (image1.is_cuda and image1.dtype == torch.float32 and image2.dtype == torch.float32 and image1.shape == image2.shape
+                and image1.dim() == 4 and not torch.is_grad_enabled()):
+            B = image1.shape[0]
+            a = image1 if image1[0].is_contiguous() else image1.contiguous()
+            b = image2 if image2[0].is_contiguous() else image2.contiguous()
+            both = torch.empty((2 * B,) + tuple(image1.shape[1:]), device=image1.device, dtype=torch.float32)
+            rc = _ffi.lib().dkt_normalize_pair(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), both.data_ptr(), B,
+                                               a[0].numel(), _ffi.device_of(a), _ffi.stream_of(a))
+            _ffi.check(rc, "dkt_normalize_pair")
+            return both[:B], both[B:], both
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        return image1, image2, None
+
+    def _encode(self, image1, image2):
+        image1, image2, both = self._normalized_pair(image1, image2)
         n = self.args.n_gru_layers
+        fnet_in = [image1, image2] if both is None else both
+        split = lambda f: f if both is None else f.split(split_size=image1.shape[0], dim=0)
         if self.encoder_streams and image1.is_cuda:
             # the two encoders are independent: fnet runs on a second stream beside cnet (the
             # small layers of either one leave CUs idle); joined before anything consumes fmaps
@@ -166,12 +187,12 @@ class RAFTStereo(nn.Module):
             side = _side_stream(image1.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                fmap1, fmap2 = self.fnet([image1, image2])
+                fmap1, fmap2 = split(self.fnet(fnet_in))
             cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
             main.wait_stream(side)
         else:
             cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
-            fmap1, fmap2 = self.fnet([image1, image2])
+            fmap1, fmap2 = split(self.fnet(fnet_in))
         net_list = [x[0] for x in cnet_list]
         inp_list = [x[1] for x in cnet_list]
         return fmap1.float(), fmap2.float(), net_list, inp_list
@@ -561,10 +582,53 @@ class RAFTStereo(nn.Module):
     #: non-finite output instead of saturating it; this is where that becomes an error.
     check_finite = True
 
-    @torch.no_grad()
+    def _forward_train(self, image1, image2, iters, flow_init):
+        """raft_stereo.py:85-187 with test_mode=False: the up-sampled disparity of EVERY iteration (the sequence loss of
+        tools/ft_dkt.py:223-242 weighs them), differentiable end to end.  The correlation block and the update operator run
+        on this library's kernels as autograd nodes (corr._BuildFn / _LookupFn, conv.conv2d_autograd); the encoders' layers
+        fall back to torch wherever their weights need gradients (extractor._Conv2d)."""
+        args = self.args
+        n = args.n_gru_layers
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        cnet_list = self.cnet(image1, num_layers=n)
+        fmap1, fmap2 = self.fnet([image1, image2])
+        net_list = [torch.tanh(x[0]) for x in cnet_list]
+        inp_list = [list(_conv.conv2d_autograd(torch.relu(x[1]), conv).split(split_size=conv.out_channels // 3, dim=1))
+                    for x, conv in zip(cnet_list, self.context_zqr_convs)]
+        corr_fn = CORR_IMPLEMENTATIONS[args.corr_implementation](fmap1.float(), fmap2.float(), radius=args.corr_radius,
+                                                                 num_levels=args.corr_levels)
+        b, _, h, w = net_list[0].shape
+        coords0 = coords_grid(b, h, w).to(fmap1.device)
+        coords1 = coords0.clone()
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+        predictions = []
+        for _ in range(iters):
+            coords1 = coords1.detach()                                   # raft_stereo.py:153
+            corr = corr_fn(coords1)
+            flow = coords1 - coords0
+            if n == 3 and args.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+            if n >= 2 and args.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=(n == 3), iter16=True, iter08=False, update=False)
+            net_list, up_mask, delta_flow = self.update_block(net_list, inp_list, corr, flow, iter32=(n == 3), iter16=(n >= 2))
+            # stereo: project the update onto the epipolar line (raft_stereo.py:165), without writing into an autograd output
+            delta_flow = torch.cat([delta_flow[:, :1], torch.zeros_like(delta_flow[:, 1:])], dim=1)
+            coords1 = coords1 + delta_flow
+            predictions.append(self.upsample_flow(coords1 - coords0, up_mask)[:, :1])
+        return predictions
+
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
         if not test_mode:
-            raise NotImplementedError("dkt_stereo_amd.RAFTStereo is the inference (test_mode=True) path")
+            if not torch.is_grad_enabled():
+                raise NotImplementedError("dkt_stereo_amd.RAFTStereo: test_mode=False is the training forward (autograd "
+                                          "enabled); inference is test_mode=True")
+            return self._forward_train(image1, image2, iters, flow_init)
+        with torch.no_grad():
+            return self._forward_test(image1, image2, iters, flow_init)
+
+    def _forward_test(self, image1, image2, iters, flow_init):
         with GPU_GUARD.shared():                      # another thread's graph capture waits for this pass, and vice versa
             fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
             flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)

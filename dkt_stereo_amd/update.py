@@ -30,7 +30,7 @@ import torch.nn.functional as F
 
 from . import _ffi
 from .conv import (_CACHE_LOCK, conv2d, conv2d_accumulate, conv2d_gate_out, conv2d_gate_out_pair, conv2d_gate_zr,
-                   conv2d_gate_zr_pair, conv2d_pair, few_eligible, get_backend, hip_eligible, pair_eligible)
+                   conv2d_autograd, conv2d_gate_zr_pair, conv2d_pair, few_eligible, get_backend, hip_eligible, pair_eligible)
 
 
 class _Harness(threading.local):
@@ -545,8 +545,64 @@ class BasicMultiUpdateBlock(nn.Module):
                 net[0] = fine(net[0], *(inp[0]), mf, out=o(net[0]))
         return net
 
+    # ---- autograd path (training through the update operator, tools/ft_dkt.py:223-242; VERDICT r02 missing #2) -------
+    def _wants_grad(self, net, inp, corr, aux):
+        if not torch.is_grad_enabled():
+            return False
+        ts = [t for t in list(net) + [t for scale in inp for t in scale] + [corr, aux] if torch.is_tensor(t)]
+        return any(t.requires_grad for t in ts) or any(p.requires_grad for p in self.parameters())
+
+    @staticmethod
+    def _gru_autograd(gru, h, cz, cr, cq, *xs):
+        """core/update.py:23-32 on differentiable convolutions (conv.conv2d_autograd); z and r share one convolution."""
+        hx = torch.cat([h, *xs], dim=1)
+        zr = SimpleNamespace(weight=torch.cat([gru.convz.weight, gru.convr.weight], 0),
+                             bias=torch.cat([gru.convz.bias, gru.convr.bias], 0), padding=gru.convz.padding)
+        a = conv2d_autograd(hx, zr)
+        ch = h.shape[1]
+        z = torch.sigmoid(a[:, :ch] + cz)
+        r = torch.sigmoid(a[:, ch:] + cr)
+        q = torch.tanh(conv2d_autograd(torch.cat([r * h, *xs], dim=1), gru.convq) + cq)
+        return (1 - z) * h + z * q
+
+    def _encoder_autograd(self, aux, corr):
+        e = self.encoder
+        if hasattr(corr, "materialize"):
+            corr = corr.materialize()
+        cor = conv2d_autograd(conv2d_autograd(corr, e.convc1, relu=True), e.convc2, relu=True)
+        b1, b2 = (getattr(e, n) for n in e._branch)
+        aux_f = conv2d_autograd(conv2d_autograd(aux, b1, relu=True), b2, relu=True)
+        return torch.cat([conv2d_autograd([cor, aux_f], e.conv, relu=True), aux], dim=1)
+
+    def _stack_autograd(self, net, inp, grus, aux, corr, flags):
+        """core/update.py:115-133 (IGEV: igev_stereo/update.py:122-135): coarse to fine, every operator an autograd node."""
+        n = self.args.n_gru_layers
+        fine, mid, coarse = grus
+        it_fine, it_mid, it_coarse = flags
+        net = list(net)
+        p2 = lambda t: F.avg_pool2d(t, 3, stride=2, padding=1)
+        up = lambda t, dest: F.interpolate(t, dest.shape[2:], mode="bilinear", align_corners=True)
+        if it_coarse:
+            net[2] = self._gru_autograd(coarse, net[2], *inp[2], p2(net[1]))
+        if it_mid:
+            xs = [p2(net[0])] + ([up(net[2], net[1])] if n > 2 else [])
+            net[1] = self._gru_autograd(mid, net[1], *inp[1], *xs)
+        if it_fine:
+            mf = self._encoder_autograd(aux, corr)
+            xs = [mf] + ([up(net[1], net[0])] if n > 1 else [])
+            net[0] = self._gru_autograd(fine, net[0], *inp[0], *xs)
+        return net
+
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True,
                 update=True, need_mask=True):
+        if self._wants_grad(net, inp, corr, flow):
+            net = self._stack_autograd(net, inp, (self.gru08, self.gru16, self.gru32), flow, corr, (iter08, iter16, iter32))
+            if not update:
+                return net
+            fh = self.flow_head
+            delta_flow = conv2d_autograd(conv2d_autograd(net[0], fh.conv1, relu=True), fh.conv2)
+            mask = .25 * conv2d_autograd(conv2d_autograd(net[0], self.mask[0], relu=True), self.mask[2]) if need_mask else None
+            return net, mask, delta_flow
         net = self._gru_stack(net, inp, self.gru08, self.gru16, self.gru32,
                               lambda: self.encoder(flow, corr), iter08, iter16, iter32)
         if not update:
@@ -581,6 +637,14 @@ class BasicMultiUpdateBlockIGEV(BasicMultiUpdateBlock):
 
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True,
                 update=True, need_mask=True):
+        if self._wants_grad(net, inp, corr, disp):
+            net = self._stack_autograd(net, inp, (self.gru04, self.gru08, self.gru16), disp, corr, (iter04, iter08, iter16))
+            if not update:
+                return net
+            dh = self.disp_head
+            delta_disp = conv2d_autograd(conv2d_autograd(net[0], dh.conv1, relu=True), dh.conv2)
+            mask_feat_4 = conv2d_autograd(net[0], self.mask_feat_4[0], relu=True) if need_mask else None
+            return net, mask_feat_4, delta_disp
         net = self._gru_stack(net, inp, self.gru04, self.gru08, self.gru16,
                               lambda: self.encoder(disp, corr), iter04, iter08, iter16)
         if not update:

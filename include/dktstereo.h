@@ -500,6 +500,11 @@ int dkt_instance_norm_join_c8(const float *c, const float *c_mean_invstd, int c_
                               const float *a, const float *a_mean_invstd, int a_relu,
                               float *y, void *dst, long dst_bstride_bytes, int ch0, float act_scale,
                               int B, int C, int H, int W, int device, void *stream);
+/* Input normalisation of a stereo pair in one pass (meta_arch/raft_stereo/raft_stereo.py:91-92):
+ * out[0:B] = 2*(image1/255) - 1, out[B:2B] = 2*(image2/255) - 1, out = (2B, C, H, W) dense -- the feature encoder's
+ * concatenated batch (core/extractor.py:180-183).  image*_bstride / per_image in floats (per_image = C*H*W, dense per item). */
+int dkt_normalize_pair(const float *image1, long image1_bstride, const float *image2, long image2_bstride,
+                       float *out, int B, long per_image, int device, void *stream);
 /* IGEV's geometry-encoding lookup (dkt_geo_lookup; meta_arch/igev_stereo/geometry.py:29-69) fused with the motion
  * encoder's 1x1 layer (convc1, igev_stereo/update.py:78,86): out[b, co] = [relu](bias[co] + sum_k weight_t[k][co] *
  * lookup[b, k]) -- the L*(2r+1)*(C+1)-channel lookup is never written.  weight_t: (L*(2r+1)*(C+1), Cout) k-major, k in the

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _rel(a, b):
-    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / b.abs().max())
 
 
 def _c8():
@@ -402,3 +403,135 @@ def test_geo_lookup_fused_with_convc1(shape):
         assert torch.equal(fn.lookup_conv1x1(wide[:, 2:], coords, layer, relu=True), out)
     # configurations outside the fused form are declined (the caller runs the two steps)
     assert fn.lookup_conv1x1(disp, coords, torch.nn.Conv2d(162, 96, 1).to(DEV)) is None
+
+
+@pytest.mark.parametrize("case", [(2, 24, 40, 3, 48, 40), (1, 33, 37, 1, 36, 64), (1, 20, 28, 7, 2, 64), (1, 40, 72, 3, 384, 256)])
+def test_conv2d_autograd_matches_torch(case):
+    """conv.conv2d_autograd (forward and input gradient on this library's kernels, weight gradient on the vendor library)
+    against torch's autograd of F.conv2d in fp64: value, d/dx, d/dw, d/db; with and without the fused ReLU."""
+    from dkt_stereo_amd import conv
+    B, H, W, k, cin, cout = case
+    torch.manual_seed(7)
+    layer = torch.nn.Conv2d(cin, cout, k, padding=k // 2).to(DEV)
+    x0 = torch.randn(B, cin, H, W, device=DEV)
+    gy = torch.randn(B, cout, H, W, device=DEV)
+    for relu in (False, True):
+        x = x0.clone().requires_grad_(True)
+        y = conv.conv2d_autograd(x, layer, relu=relu)
+        gx, gw, gb = torch.autograd.grad(y, [x, layer.weight, layer.bias], gy)
+        xd = x0.double().requires_grad_(True)
+        wd, bd = layer.weight.detach().double().requires_grad_(True), layer.bias.detach().double().requires_grad_(True)
+        yd = F.conv2d(xd, wd, bd, padding=k // 2)
+        yd = F.relu(yd) if relu else yd
+        gxd, gwd, gbd = torch.autograd.grad(yd, [xd, wd, bd], gy.double())
+        assert _rel(y, yd) <= 3e-6 and _rel(gx, gxd) <= 5e-6 and _rel(gw, gwd) <= 2e-5 and _rel(gb, gbd) <= 2e-5, \
+            (case, relu, _rel(y, yd), _rel(gx, gxd), _rel(gw, gwd), _rel(gb, gbd))
+
+
+@pytest.mark.parametrize("igev", [False, True])
+def test_update_block_autograd_matches_oracle(igev):
+    """Training through the update operator (tools/ft_dkt.py:223-242): one update-block call with autograd enabled --
+    values and the gradients of a scalar loss with respect to the hidden states, the correlation features and a sample of
+    the parameters -- against the CPU oracle's autograd (the oracle is pinned on the reference's modules)."""
+    from types import SimpleNamespace
+    from oracle import torch_oracle as to
+    from dkt_stereo_amd.update import BasicMultiUpdateBlock, BasicMultiUpdateBlockIGEV
+    cfg = dict(corr_levels=2 if igev else 4, corr_radius=4, n_downsample=2, n_gru_layers=3, hidden_dims=[128, 128, 128],
+               slow_fast_gru=False)
+    cls = BasicMultiUpdateBlockIGEV if igev else BasicMultiUpdateBlock
+    blk = cls(SimpleNamespace(**cfg), hidden_dims=cfg["hidden_dims"])
+    sd = _synth.torch_state_dict(_synth.shapes_of(blk), 21)
+    blk.load_state_dict(sd)
+    blk.to(DEV)
+    H, W = 16, 24
+    torch.manual_seed(8)
+    net0 = [torch.tanh(torch.randn(1, 128, H >> i, W >> i)) for i in range(3)]
+    inp = [[0.5 * torch.randn(1, 128, H >> i, W >> i) for _ in range(3)] for i in range(3)]
+    corr0 = torch.randn(1, 162 if igev else 36, H, W)
+    aux = torch.randn(1, 1 if igev else 2, H, W)
+    wts = [torch.randn(1, 128, H >> i, W >> i) for i in range(3)]
+    wd = torch.randn(1, 1 if igev else 2, H, W)
+    wm = torch.randn(1, 32 if igev else 144, H, W)
+    names = ["encoder.convc1.weight", "encoder.conv.bias", ("gru04" if igev else "gru08") + ".convz.weight",
+             ("gru08" if igev else "gru16") + ".convq.weight", ("gru16" if igev else "gru32") + ".convr.bias",
+             ("disp_head" if igev else "flow_head") + ".conv2.weight", ("mask_feat_4.0" if igev else "mask.0") + ".weight"]
+
+    def loss_of(net, mask, delta, to_dev):
+        t = lambda a: a.to(to_dev)
+        return sum((n * t(w)).sum() for n, w in zip(net, wts)) + (delta * t(wd)).sum() + (mask * t(wm)).sum()
+
+    # ---- ours (GPU)
+    net_g = [t.to(DEV).requires_grad_(True) for t in net0]
+    corr_g = corr0.to(DEV).requires_grad_(True)
+    kw = dict(disp=aux.to(DEV)) if igev else dict(flow=aux.to(DEV))
+    net, mask, delta = blk(list(net_g), [[t.to(DEV) for t in s] for s in inp], corr_g, **kw)
+    params = dict(blk.named_parameters())
+    got = torch.autograd.grad(loss_of(net, mask, delta, DEV), net_g + [corr_g] + [params[n] for n in names])
+    # ---- oracle (CPU, fp64)
+    sdd = {("ub." + k): v.double().requires_grad_(True) for k, v in sd.items()}
+    net_c = [t.double().requires_grad_(True) for t in net0]
+    corr_c = corr0.double().requires_grad_(True)
+    o_net, o_mask, o_delta = to.update_block(sdd, "ub", 3, list(net_c), [[t.double() for t in s] for s in inp], corr_c,
+                                             aux.double(), igev=igev)
+    want = torch.autograd.grad(loss_of(o_net, o_mask, o_delta, "cpu"), net_c + [corr_c] + [sdd["ub." + n] for n in names])
+    for a, b in zip(list(net) + [mask, delta], list(o_net) + [o_mask, o_delta]):
+        assert _rel(a.detach().cpu(), b.detach()) <= 1e-5
+    for name, a, b in zip(["net0", "net1", "net2", "corr"] + names, got, want):
+        assert _rel(a.cpu(), b) <= 5e-5, (name, _rel(a.cpu(), b))
+
+
+def test_raft_training_forward_matches_inference_and_oracle_gradients():
+    """RAFTStereo.forward(test_mode=False) under autograd (tools/ft_dkt.py:223): the last of the per-iteration predictions
+    equals the test_mode result; after ONE iteration (no detach inside the chain) the gradients of a scalar loss with respect
+    to parameters of the update block, the context convolutions and the last layer of either encoder match the CPU oracle's
+    autograd.  (The encoders' other layers are frozen here: trainable ones fall back to torch layer by layer, which works
+    but spends minutes in the vendor library's kernel search on a fresh box.)"""
+    from oracle import torch_oracle as to
+    from dkt_stereo_amd.raft_stereo import BASE_CONFIG
+    model, sd = _raft(DEV)
+    names = ["update_block.gru08.convz.weight", "update_block.gru16.convq.bias", "update_block.encoder.convc1.bias",
+             "update_block.flow_head.conv2.weight", "update_block.mask.2.weight", "context_zqr_convs.0.weight",
+             "fnet.conv2.weight", "cnet.outputs08.0.1.weight"]
+    for n, p in model.named_parameters():
+        if (n.startswith("fnet.") or n.startswith("cnet.")) and n not in names:
+            p.requires_grad_(False)
+    i1, i2 = _synth.image_pair(5, 1, 64, 128, 12)
+    g1, g2 = G(i1), G(i2)
+    with torch.no_grad():
+        _, want_up = model(g1, g2, iters=3, test_mode=True)
+    preds = model(g1, g2, iters=3, test_mode=False)
+    assert len(preds) == 3 and preds[-1].requires_grad
+    assert maxabs(preds[-1].detach(), want_up) <= 1e-4
+    wl = torch.randn(1, 1, 64, 128, generator=torch.Generator().manual_seed(9))
+    params = dict(model.named_parameters())
+    pred = model(g1, g2, iters=1, test_mode=False)[0]
+    got = torch.autograd.grad((pred * wl.to(DEV)).sum(), [params[n] for n in names])
+    sdd = {k: v.clone() for k, v in sd.items()}
+    for n in names:
+        sdd[n].requires_grad_(True)
+    fm1, fm2, net, inp = to.raft_prepare(sdd, dict(BASE_CONFIG), torch.from_numpy(i1), torch.from_numpy(i2))
+    _, o_up = to.raft_iterations(sdd, dict(BASE_CONFIG), fm1, fm2, net, inp, 1)
+    want = torch.autograd.grad((o_up * wl).sum(), [sdd[n] for n in names])
+    assert maxabs(pred.detach(), o_up.detach()) <= 1e-4
+    for n, a, b in zip(names, got, want):
+        assert _rel(a.cpu(), b) <= 5e-4, (n, _rel(a.cpu(), b))
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        model(g1, g2, iters=1, test_mode=False)
+
+
+@torch.no_grad()
+def test_normalize_pair_is_the_reference_arithmetic():
+    """dkt_normalize_pair: 2 * (x / 255) - 1 for both images into the feature encoder's concatenated batch, bit for bit the
+    reference's CPU arithmetic (raft_stereo.py:91-92); also from batch-strided views."""
+    from dkt_stereo_amd.raft_stereo import RAFTStereo
+    torch.manual_seed(10)
+    a, b = torch.rand(2, 3, 40, 72, device=DEV) * 255, torch.rand(2, 3, 40, 72, device=DEV) * 255
+    n1, n2, both = RAFTStereo._normalized_pair(a, b)
+    assert both is not None and both.shape == (4, 3, 40, 72)
+    # the reference arithmetic is the CPU's (true division; torch's GPU kernel multiplies by a rounded 1/255 instead)
+    ref = lambda t: 2 * (t.cpu() / 255.0) - 1.0
+    assert torch.equal(n1.cpu(), ref(a)) and torch.equal(n2.cpu(), ref(b))
+    assert torch.equal(both, torch.cat([n1, n2], 0)) and n1.data_ptr() == both.data_ptr()
+    wide = torch.rand(2, 2, 3, 40, 72, device=DEV) * 255
+    m1, m2, _ = RAFTStereo._normalized_pair(wide[:, 0], wide[:, 1])
+    assert torch.equal(m1.cpu(), ref(wide[:, 0])) and torch.equal(m2.cpu(), ref(wide[:, 1]))
