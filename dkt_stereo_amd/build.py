@@ -21,7 +21,10 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 # SLP build of conv3x3_few_kernel returned wrong low halves of its packed accumulators (lanes 48..63) whenever its
 # block shared a CU with a block of the MFMA convolution (tools/stress_lds_dma.py: 1000/1200 launches wrong
 # with packed math, 0/1200 with scalar math under the same co-residency).
-EXTRA_FLAGS = {"conv_direct": ["-fno-slp-vectorize"]}
+# conv_c8: its step and epilogue are fully unrolled by construction (accumulators and fragments must stay in registers: a loop
+# the unroller gives up on indexes them dynamically and sends the 128 accumulators to scratch -- 540 us instead of 280);
+# the epilogue's body exceeds the default threshold of `#pragma unroll`.
+EXTRA_FLAGS = {"conv_direct": ["-fno-slp-vectorize"], "conv_c8": ["-mllvm", "-pragma-unroll-threshold=100000"]}
 
 
 def sources():

@@ -396,6 +396,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     float v[2][4];
+                    // the fp32 operands of the fused epilogues (gate terms, state, residual) of both channel groups of this
+                    // pair are fetched BEFORE the pair's first store: interleaved with the stores, as they were, every group's
+                    // loads waited behind the previous group's stores (a load cannot move above a store that may alias it) and
+                    // the epilogue was a chain of 32 memory round trips per wave: z|r 283 -> 273 us, q 166 -> 159.  All four
+                    // groups of an accumulator block at once spill 31 registers beside the accumulators and the next tile's
+                    // prefetched fragments and measured 286 us.
+                    float gca[2][4], gha[2][4], gza[2][4];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int cl = cw + m * 32 + 8 * (2 * jp + jj) + 4 * kg;
+                        if (a.epi != 0) f32_load4(f32_ptr(pc, cl < cout_eff ? cl : 0, px, iHW), iHW, gca[jj]);
+                        else gca[jj][0] = gca[jj][1] = gca[jj][2] = gca[jj][3] = 0.0f;
+                        if (ph) f32_load4(f32_ptr(ph, cl, px, iHW), iHW, gha[jj]);
+                        else gha[jj][0] = gha[jj][1] = gha[jj][2] = gha[jj][3] = 0.0f;
+                        if (pz) f32_load4(f32_ptr(pz, cl, px, iHW), iHW, gza[jj]);
+                        else gza[jj][0] = gza[jj][1] = gza[jj][2] = gza[jj][3] = 0.0f;
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * jp + jj;
@@ -415,10 +432,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                                 v[jj][i] = y;
                             }
                         } else {
-                            float gc[4], gh[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
-                            f32_load4(f32_ptr(pc, cl < cout_eff ? cl : 0, px, iHW), iHW, gc);
-                            if (ph) f32_load4(f32_ptr(ph, cl, px, iHW), iHW, gh);
-                            if (pz) f32_load4(f32_ptr(pz, cl, px, iHW), iHW, gz);
+                            float gc[4], gh[4], gz[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                gc[i] = gca[jj][i];
+                                gh[i] = gha[jj][i];
+                                gz[i] = gza[jj][i];
+                            }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 if (a.epi == 1) {
