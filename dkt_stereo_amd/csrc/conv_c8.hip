@@ -399,9 +399,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                     // the fp32 operands of the fused epilogues (gate terms, state, residual) of both channel groups of this
                     // pair are fetched BEFORE the pair's first store: interleaved with the stores, as they were, every group's
                     // loads waited behind the previous group's stores (a load cannot move above a store that may alias it) and
-                    // the epilogue was a chain of 32 memory round trips per wave: z|r 283 -> 273 us, q 166 -> 159.  All four
-                    // groups of an accumulator block at once spill 31 registers beside the accumulators and the next tile's
-                    // prefetched fragments and measured 286 us.
+                    // the epilogue's loads queued behind its stores.  Worth 2 us of the z|r layer's 274 in an interleaved
+                    // same-box A/B (tools/c8_ab.py); all four groups of an accumulator block at once spill 31 registers
+                    // beside the accumulators and the next tile's prefetched fragments and are slower.
                     float gca[2][4], gha[2][4], gza[2][4];
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
