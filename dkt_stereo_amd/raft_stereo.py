@@ -621,9 +621,8 @@ class RAFTStereo(nn.Module):
 
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
         if not test_mode:
-            if not torch.is_grad_enabled():
-                raise NotImplementedError("dkt_stereo_amd.RAFTStereo: test_mode=False is the training forward (autograd "
-                                          "enabled); inference is test_mode=True")
+            # the reference's default: the list of every iteration's prediction (differentiable when autograd is enabled;
+            # under torch.no_grad() the same loop on the inference kernels, without the captured-graph fast path)
             return self._forward_train(image1, image2, iters, flow_init)
         with torch.no_grad():
             return self._forward_test(image1, image2, iters, flow_init)
