@@ -385,6 +385,10 @@ def main():
                                "corr_implementation=reg, BASELINE.json configs[1]"
                                % (args.height, args.width, h4, w4, args.iters, B),
                    "parallelism": "dp%d (independent pairs per rank, result gather only)" % world,
+                   # the N = 1 line is BASELINE.json configs[1] (batch 1); N > 1 runs configs[3]'s per-GPU share (batch 8 per
+                   # GPU): its weak-scaling reference is `--gpus 1 --batch 8` (profiles/r03_bench_lines.jsonl, line 2)
+                   "per_gpu_batch": B,
+                   "weak_scaling_reference": "bench.py --gpus 1 --batch %d" % B,
                    "conv_backend": conv_backend_name,
                    "loop": "C8S convolutions (loop_c8.py)" if c8_used else "round-2 kernels"},
         # dominant kernel (~70 % of a pair): the split-fp16 implicit-GEMM convolution.  It is
