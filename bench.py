@@ -389,7 +389,8 @@ def main():
                    # GPU): its weak-scaling reference is `--gpus 1 --batch 8` (profiles/r03_bench_lines.jsonl, line 2)
                    "per_gpu_batch": B,
                    "weak_scaling_reference": "bench.py --gpus 1 --batch %d" % B,
-                   "conv_backend": conv_backend_name,
+                   "conv_backend": (conv_backend_name.replace("dkt_conv2d_f16s", "refinement loop: dkt_conv2d_c8, encoders: dkt_conv2d_f16s")
+                                    if c8_used else conv_backend_name),
                    "loop": "C8S convolutions (loop_c8.py)" if c8_used else "round-2 kernels"},
         # dominant kernel (~70 % of a pair): the split-fp16 implicit-GEMM convolution.  It is
         # MFMA-bound; `achieved` counts the fp16 MFMA flops it executes per launch
