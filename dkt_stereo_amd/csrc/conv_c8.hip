@@ -393,26 +393,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                 const int oh = h0 + wn * NF + n, ow = w0 + li;
                 const bool inside = oh < a.H && ow < a.W;
                 const long px = inside ? (long)oh * a.W + ow : 0;
+                // The fp32 operands of the fused epilogues (gate terms, state, residual) of all four channel groups of this
+                // accumulator block are fetched BEFORE the block's first store.  Interleaved with the stores, as they were, a
+                // group's loads waited behind the previous group's stores (a load cannot move above a store that may alias
+                // it): the epilogue was a chain of memory round trips -- counters of an epilogue-only launch: 57 % of the wave
+                // cycles in s_waitcnt (tools/c8_epi_pmc.sh) -- 32 per wave, 8 now.  The registers come from the next tile's
+                // prefetched fragments, which are re-read after the epilogue instead of being held across it.
+                float gca[4][4], gha[4][4], gza[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cl = cw + m * 32 + 8 * j + 4 * kg;
+                    if (a.epi != 0) f32_load4(f32_ptr(pc, cl < cout_eff ? cl : 0, px, iHW), iHW, gca[j]);
+                    else gca[j][0] = gca[j][1] = gca[j][2] = gca[j][3] = 0.0f;
+                    if (ph) f32_load4(f32_ptr(ph, cl, px, iHW), iHW, gha[j]);
+                    else gha[j][0] = gha[j][1] = gha[j][2] = gha[j][3] = 0.0f;
+                    if (pz) f32_load4(f32_ptr(pz, cl, px, iHW), iHW, gza[j]);
+                    else gza[j][0] = gza[j][1] = gza[j][2] = gza[j][3] = 0.0f;
+                }
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     float v[2][4];
-                    // the fp32 operands of the fused epilogues (gate terms, state, residual) of both channel groups of this
-                    // pair are fetched BEFORE the pair's first store: interleaved with the stores, as they were, every group's
-                    // loads waited behind the previous group's stores (a load cannot move above a store that may alias it) and
-                    // the epilogue's loads queued behind its stores.  Worth 2 us of the z|r layer's 274 in an interleaved
-                    // same-box A/B (tools/c8_ab.py); all four groups of an accumulator block at once spill 31 registers
-                    // beside the accumulators and the next tile's prefetched fragments and are slower.
-                    float gca[2][4], gha[2][4], gza[2][4];
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int cl = cw + m * 32 + 8 * (2 * jp + jj) + 4 * kg;
-                        if (a.epi != 0) f32_load4(f32_ptr(pc, cl < cout_eff ? cl : 0, px, iHW), iHW, gca[jj]);
-                        else gca[jj][0] = gca[jj][1] = gca[jj][2] = gca[jj][3] = 0.0f;
-                        if (ph) f32_load4(f32_ptr(ph, cl, px, iHW), iHW, gha[jj]);
-                        else gha[jj][0] = gha[jj][1] = gha[jj][2] = gha[jj][3] = 0.0f;
-                        if (pz) f32_load4(f32_ptr(pz, cl, px, iHW), iHW, gza[jj]);
-                        else gza[jj][0] = gza[jj][1] = gza[jj][2] = gza[jj][3] = 0.0f;
-                    }
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const int j = 2 * jp + jj;
@@ -435,9 +435,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                             float gc[4], gh[4], gz[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                gc[i] = gca[jj][i];
-                                gh[i] = gha[jj][i];
-                                gz[i] = gza[jj][i];
+                                gc[i] = gca[j][i];
+                                gh[i] = gha[j][i];
+                                gz[i] = gza[j][i];
                             }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
@@ -588,6 +588,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
 #pragma unroll
         for (int j = 0; j < NIA; ++j) aoff_cur[j] = aoff_nxt[j];
         zero_acc();
+        // The fragments the last step fetched for this tile's first step are fetched AGAIN here (their LDS images are
+        // untouched: no DMA is issued during the epilogue): that makes the 16 + 8 NF fragment registers dead across the
+        // epilogue, which needs them for its operand batches (see epilogue()).
+        {
+            const unsigned aw = lds_w_addr + sl * WSLOT, ab = lds_b_addr + (g & 1) * ACT_BYTES;
+            C8_RD(Alo[0], 2048, aw) C8_RD(Alo[1], 2048 + 512, aw)
+            C8_RD(Bhi[0], C8_ROW(0, 0, 0), ab)
+            if constexpr (NF > 1) C8_RD(Bhi[1], C8_ROW(1, 0, 0), ab)
+            if constexpr (NF > 2) C8_RD(Bhi[2], C8_ROW(2, 0, 0), ab)
+            if constexpr (NF > 3) C8_RD(Bhi[3], C8_ROW(3, 0, 0), ab)
+            C8_RDL(Blo[0], C8_ROW(0, 0, NPP * 16), ab)
+            if constexpr (NF > 1) C8_RDL(Blo[1], C8_ROW(1, 0, NPP * 16), ab)
+            if constexpr (NF > 2) C8_RDL(Blo[2], C8_ROW(2, 0, NPP * 16), ab)
+            if constexpr (NF > 3) C8_RDL(Blo[3], C8_ROW(3, 0, NPP * 16), ab)
+            c8_wait_lgkm<0>();
+        }
     }
     c8_wait_vm<0>();        // no DMA may land in this block's LDS after it has been released
 }
