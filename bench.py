@@ -271,6 +271,24 @@ def main():
             conv_events.append((ea, eb))
             c8_used.append((d1.H, d1.W, d1.Cout, sum(d1.src_channels[i] for i in range(d1.nsrc)), cfg))
 
+        # round-4 loop: the whole ConvGRU step (z|r -> gates -> q -> h') of gru08, with gru32 of the next iteration riding
+        # along, is ONE launch of gru_c8_kernel (dkt_gru_c8_pair)
+        real_gru = dc8.gru_launch
+        gru_used = []
+
+        def timed_gru(d0, d1=None, err=None, ref=None):
+            if d0.H != h4 or d1 is None:
+                return real_gru(d0, d1, err=err, ref=ref)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            ok = real_gru(d0, d1, err=err, ref=ref)
+            eb.record()
+            if ok:
+                conv_events.append((ea, eb))
+                gru_used.append((sum(d0.x_channels[i] for i in range(d0.nx)), d1.H, d1.W, sum(d1.x_channels[i] for i in range(d1.nx))))
+            return ok
+
+        dc8.gru_launch = timed_gru
         dc8.launch_pair = timed_pair
         upd.conv2d_gate_zr = timed_gate_zr
         model.c8_eager = c8_loop
@@ -278,6 +296,7 @@ def main():
         torch.cuda.synchronize()
         model.c8_eager = False
         dc8.launch_pair = real_pair
+        dc8.gru_launch = real_gru
         upd.conv2d_gate_zr = real_gate_zr
         dcorr.CorrBlock1D.lookup_conv1x1 = real_fused
         rs.CORR_IMPLEMENTATIONS = real_impls
@@ -348,6 +367,13 @@ def main():
         conv_alg_flops += 2.0 * B * h2 * w2 * ci2 * 9 * co2
         conv_kernel = ("conv_c8_kernel<4,2,4,4> (dkt_conv2d_c8_pair, tile shape %d): gru08 z|r 384->256 3x3 @%dx%d + gru32 z|r "
                        "%d->%d @%dx%d, gate epilogues, C8S operands" % (cfg2, h4, w4, ci2, co2, h2, w2))
+    if gru_used:
+        # one launch = both convolutions of the finest ConvGRU (z|r: 128 + x -> 256, q: 128 + x -> 128) and of the coarsest
+        xc, h2, w2, xc2 = gru_used[0]
+        conv_alg_flops = 2.0 * n_pix * (128 + xc) * 9 * 384 + 2.0 * B * h2 * w2 * (128 + xc2) * 9 * 384
+        conv_kernel = ("gru_c8_kernel (dkt_gru_c8_pair): one ConvGRU step per launch -- gru08 z|r %d->256 + gates + q %d->128 + "
+                       "state update @%dx%d, with gru32 (%d->256, %d->128 @%dx%d) riding along; C8S operands, z in registers, "
+                       "neighbour-tile flags instead of a kernel boundary" % (128 + xc, 128 + xc, h4, w4, 128 + xc2, 128 + xc2, h2, w2))
     conv_tflops_exec = passes * conv_alg_flops / (conv_avg_ms * 1e-3) / 1e12 if conv_avg_ms > 0 else 0.0
     # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     # rocprofv3 runs of the same kernels on the same shapes); None when the file is absent
@@ -355,8 +381,8 @@ def main():
     try:
         # round 3's passes measured the C8S kernels (conv_c8_kernel, corr_feat64_kernel); the round-2 kernels' figures
         # (other conv backends, small images) are in the round-2 file
-        name = "r03_hbm_traffic.json" if c8_used else "r02_hbm_traffic.json"
-        if not os.path.exists(os.path.join(ROOT, "profiles", name)):
+        name = "r04_hbm_traffic.json" if gru_used else "r03_hbm_traffic.json" if c8_used else "r02_hbm_traffic.json"
+        if not gru_used and not os.path.exists(os.path.join(ROOT, "profiles", name)):
             name = "r02_hbm_traffic.json"
         with open(os.path.join(ROOT, "profiles", name)) as f:
             traffic = json.load(f)
@@ -390,8 +416,9 @@ def main():
                    "per_gpu_batch": B,
                    "weak_scaling_reference": "bench.py --gpus 1 --batch %d" % B,
                    "conv_backend": (conv_backend_name.replace("dkt_conv2d_f16s", "refinement loop: dkt_conv2d_c8, encoders: dkt_conv2d_f16s")
-                                    if c8_used else conv_backend_name),
-                   "loop": "C8S convolutions (loop_c8.py)" if c8_used else "round-2 kernels"},
+                                    if (c8_used or gru_used) else conv_backend_name),
+                   "loop": ("C8S convolutions (loop_c8.py), fused ConvGRU launch" if gru_used else
+                            "C8S convolutions (loop_c8.py)" if c8_used else "round-2 kernels")},
         # dominant kernel (~70 % of a pair): the split-fp16 implicit-GEMM convolution.  It is
         # MFMA-bound; `achieved` counts the fp16 MFMA flops it executes per launch
         # (passes x 2*H*W*Cin*9*Cout; the fp32-equivalent algorithmic figure is 1/passes of it)
@@ -415,7 +442,7 @@ def main():
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
         # the kernel BASELINE.json's north_star sets the HBM target for
         "roofline_lookup": {"kernel": ("corr_feat64_kernel<4> (dkt_corr1d_lookup_conv1x1%s): pyramid lookup fused with "
-                                       "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA" % ("_c8, C8S output" if c8_used else "")) if fused_lookup
+                                       "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA" % ("_c8, C8S output" if (c8_used or gru_used) else "")) if fused_lookup
                             else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS,

@@ -48,8 +48,26 @@ class ConvC8Desc(ctypes.Structure):
                 ("head_outputs", ctypes.c_int), ("f32_c4", ctypes.c_int)]
 
 
+class GruC8Desc(ctypes.Structure):
+    """dkt_gru_c8_desc of include/dktstereo.h."""
+    _fields_ = [("h_c8", ctypes.c_void_p), ("h_c8_bstride", ctypes.c_long),
+                ("x", ctypes.c_void_p * 3), ("x_bstride", ctypes.c_long * 3), ("x_channels", ctypes.c_int * 3), ("nx", ctypes.c_int),
+                ("rh_c8", ctypes.c_void_p), ("rh_c8_bstride", ctypes.c_long),
+                ("w_zr", ctypes.c_void_p), ("w_q", ctypes.c_void_p),
+                ("bz", ctypes.c_void_p), ("br", ctypes.c_void_p), ("bq", ctypes.c_void_p),
+                ("cz", ctypes.c_void_p), ("cr", ctypes.c_void_p), ("cq", ctypes.c_void_p),
+                ("cz_bstride", ctypes.c_long), ("cr_bstride", ctypes.c_long), ("cq_bstride", ctypes.c_long),
+                ("h", ctypes.c_void_p), ("h_bstride", ctypes.c_long),
+                ("scale_zr", ctypes.c_float), ("scale_q", ctypes.c_float), ("act_scale", ctypes.c_float),
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("hidden", ctypes.c_int),
+                ("flags", ctypes.c_void_p)]
+
+
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
+    "dkt_gru_c8_flag_words": [_i, _i, _i],
+    "dkt_gru_c8": [ctypes.POINTER(GruC8Desc), _vp, _i, _vp],
+    "dkt_gru_c8_pair": [ctypes.POINTER(GruC8Desc), ctypes.POINTER(GruC8Desc), _vp, _i, _vp],
     "dkt_build_ablation": [],
     "dkt_pool2x_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_interp_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -123,7 +141,10 @@ SIGNATURES = {
     "dkt_interp_bilinear": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
 }
 #: entry points that do not return an int status
-RESTYPES = {"dkt_conv_c8_packed_bytes": ctypes.c_long, "dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
+RESTYPES = {"dkt_gru_c8_flag_words": ctypes.c_long, "dkt_conv_c8_packed_bytes": ctypes.c_long, "dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
+
+#: DKT_E_UNSUPPORTED of include/dktstereo.h
+E_UNSUPPORTED = -7
 
 _lib = None
 

@@ -24,7 +24,8 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 # conv_c8: its step and epilogue are fully unrolled by construction (accumulators and fragments must stay in registers: a loop
 # the unroller gives up on indexes them dynamically and sends the 128 accumulators to scratch -- 540 us instead of 280);
 # the epilogue's body exceeds the default threshold of `#pragma unroll`.
-EXTRA_FLAGS = {"conv_direct": ["-fno-slp-vectorize"], "conv_c8": ["-mllvm", "-pragma-unroll-threshold=100000"]}
+EXTRA_FLAGS = {"conv_direct": ["-fno-slp-vectorize"], "conv_c8": ["-mllvm", "-pragma-unroll-threshold=100000"],
+               "gru_c8": ["-mllvm", "-pragma-unroll-threshold=100000"]}
 
 
 def sources():

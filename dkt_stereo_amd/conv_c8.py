@@ -101,6 +101,107 @@ def packed_weights(layer, src_channels):
         return p
 
 
+def _pack_raw(w, src_channels):
+    """(Cout, Cin, 3, 3) fp32 -> (step images, 1 / weight scale) for sources of `src_channels` channels (Cin in that order)."""
+    L = _ffi.lib()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    if tuple(w.shape[2:]) != (3, 3) or cin != sum(src_channels):
+        raise ValueError("conv_c8: 3x3 layers only, operands carry %d channels, layer expects %d" % (sum(src_channels), cin))
+    n = len(src_channels)
+    ch = (ctypes.c_int * n)(*src_channels)
+    nbytes = L.dkt_conv_c8_packed_bytes(ch, n, cout)
+    if nbytes <= 0:
+        raise _ffi.DktError("dkt_conv_c8_packed_bytes rejected the layer shape")
+    wmax = float(w.abs().max())
+    e = 12 - math.floor(math.log2(wmax)) if wmax > 0 else 0
+    img = torch.zeros(nbytes // 2, device=w.device, dtype=torch.float16)
+    wc = w.float().contiguous()
+    rc = L.dkt_conv_c8_pack_weights(wc.data_ptr(), ch, n, cout, 2.0 ** e, img.data_ptr(), _ffi.device_of(w), _ffi.stream_of(w))
+    _ffi.check(rc, "dkt_conv_c8_pack_weights")
+    return img, 2.0 ** -e
+
+
+class _PackedGru:
+    __slots__ = ("key", "wzr", "wq", "inv_zr", "inv_q", "bz", "br", "bq")
+
+
+def gru_packed(gru, x_channels):
+    """Weights of one ConvGRU (core/update.py:16-21) for dkt_gru_c8: the z|r image with its output channels interleaved in
+    blocks of 32 (a wave holds z and r of the same hidden channels), the q image with its input channels reordered to
+    [x... | r*h] (the x chunks are consumed before the neighbours' r*h is needed).  Cached on the module per device."""
+    with _CACHE_LOCK:
+        ps = [gru.convz.weight, gru.convr.weight, gru.convq.weight, gru.convz.bias, gru.convr.bias, gru.convq.bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (tuple(x_channels),)
+        cache = gru.__dict__.setdefault("_dkt_gru_c8", {})
+        slot = (str(ps[0].device), tuple(x_channels))
+        hit = cache.get(slot)
+        if hit is not None and hit.key == key:
+            return hit
+        wz, wr, wq = (p.detach().float() for p in ps[:3])
+        ch, cin = int(wz.shape[0]), int(wz.shape[1])
+        if ch != 128 or cin != ch + sum(x_channels):
+            raise ValueError("gru_c8: hidden size 128, operands of %d channels expected" % (cin - ch))
+        wzr = torch.stack([wz.view(ch // 32, 32, cin, 3, 3), wr.view(ch // 32, 32, cin, 3, 3)], dim=1).reshape(2 * ch, cin, 3, 3)
+        wq2 = torch.cat([wq[:, ch:], wq[:, :ch]], dim=1)
+        p = _PackedGru()
+        p.wzr, p.inv_zr = _pack_raw(wzr, [ch] + list(x_channels))
+        p.wq, p.inv_q = _pack_raw(wq2, list(x_channels) + [ch])
+        p.bz, p.br, p.bq = (b.detach().float().contiguous() for b in ps[3:])
+        p.key = key
+        cache[slot] = p
+        return p
+
+
+def gru_flags(B, H, W, device):
+    """The per-tile flag words of dkt_gru_c8 for one (operator, shape) pair (zero-initialised; every launch increments them)."""
+    return torch.zeros(int(_ffi.lib().dkt_gru_c8_flag_words(B, H, W)), device=device, dtype=torch.int32)
+
+
+def gru_desc(gru, h_c8, xs, rh_c8, cz, cr, cq, h, flags):
+    """dkt_gru_c8_desc of one ConvGRU step: h (fp32 NCHW) and its C8S twin h_c8 are updated in place."""
+    xs = list(xs)
+    for s in xs + [rh_c8]:
+        if (s.H, s.W, s.B) != (h_c8.H, h_c8.W, h_c8.B) or s.scale != h_c8.scale:
+            raise ValueError("gru_c8: operands must share batch, size and activation scale")
+    HW = h_c8.H * h_c8.W
+    for t in (cz, cr, cq, h):
+        if t.shape[1:] != (128, h_c8.H, h_c8.W) or t.stride(3) != 1 or t.stride(2) != h_c8.W or t.stride(1) != HW:
+            raise ValueError("gru_c8: context terms and state are fp32 (B, 128, H, W), dense per batch item")
+    pk = gru_packed(gru, [s.C for s in xs])
+    d = _ffi.GruC8Desc()
+    d.h_c8, d.h_c8_bstride = h_c8.data_ptr(), h_c8.bstride_bytes
+    for i, s in enumerate(xs):
+        d.x[i], d.x_bstride[i], d.x_channels[i] = s.data_ptr(), s.bstride_bytes, s.C
+    d.nx = len(xs)
+    d.rh_c8, d.rh_c8_bstride = rh_c8.data_ptr(), rh_c8.bstride_bytes
+    d.w_zr, d.w_q = pk.wzr.data_ptr(), pk.wq.data_ptr()
+    d.bz, d.br, d.bq = pk.bz.data_ptr(), pk.br.data_ptr(), pk.bq.data_ptr()
+    d.cz, d.cr, d.cq = cz.data_ptr(), cr.data_ptr(), cq.data_ptr()
+    d.cz_bstride, d.cr_bstride, d.cq_bstride = cz.stride(0), cr.stride(0), cq.stride(0)
+    d.h, d.h_bstride = h.data_ptr(), h.stride(0)
+    d.scale_zr, d.scale_q, d.act_scale = pk.inv_zr / h_c8.scale, pk.inv_q / h_c8.scale, h_c8.scale
+    d.B, d.H, d.W, d.hidden = h_c8.B, h_c8.H, h_c8.W, 128
+    d.flags = flags.data_ptr()
+    d._keep = (h_c8, xs, rh_c8, pk, cz, cr, cq, h, flags)
+    return d
+
+
+def gru_launch(d0, d1=None, err=None, ref=None):
+    """One launch for one ConvGRU step (d1: a second, independent one riding in the same launch).  Returns False when the
+    device cannot run this shape in one launch (the caller falls back to gate_zr + gate_out)."""
+    ref = d0._keep[7] if ref is None else ref
+    L = _ffi.lib()
+    e = None if err is None else err.data_ptr()
+    if d1 is None:
+        rc = L.dkt_gru_c8(ctypes.byref(d0), e, _ffi.device_of(ref), _ffi.stream_of(ref))
+    else:
+        rc = L.dkt_gru_c8_pair(ctypes.byref(d0), ctypes.byref(d1), e, _ffi.device_of(ref), _ffi.stream_of(ref))
+    if rc == _ffi.E_UNSUPPORTED:
+        return False
+    _ffi.check(rc, "dkt_gru_c8")
+    return True
+
+
 def to_c4(x):
     """fp32 NCHW -> the "C4" layout [B][ceil(C/4)][H][W][4] of the epilogue-side tensors (gate operands, state, z)."""
     B, C, H, W = x.shape

@@ -25,6 +25,10 @@ if os.environ.get("DKT_C8_CFG"):
     _CFG.update(zip(("zr08", "q08", "zr16", "q16", "head", "enc", "c2"), (int(v) for v in os.environ["DKT_C8_CFG"].split(","))))
 
 
+#: round 4: the finest GRU (with the coarsest one of the next iteration riding along) as ONE launch per step (csrc/gru_c8.hip:
+#: z|r -> gates -> q -> h' per tile, neighbour flags instead of a kernel boundary); DKT_C8_FUSE_GRU=0: two launches per step
+FUSE_GRU = os.environ.get("DKT_C8_FUSE_GRU", "1") != "0"
+
 #: quarter-resolution pixels (per pair) from which the loop takes this path: the C8S kernel's tiles are 8 rows x 32 columns
 #: x 64-256 channels, smaller images leave most CUs without one (256 x 512: 7.4 ms against 5.4 on the round-2 kernels)
 MIN_PIXELS = int(os.environ.get("DKT_C8_MIN_PIXELS", "24000"))
@@ -72,6 +76,10 @@ class C8Loop:
         self.cor, self.flo = A(n0, 64), A(n0, 64)
         self.cf = A(n0, 128)
         self.hidden = torch.empty((B, 256, n0.shape[2], n0.shape[3]), device=dev, dtype=torch.float32)
+        # fused ConvGRU launches: per-tile flag words per level, one error word (a neighbour wait that timed out)
+        self.gflags = [c8.gru_flags(B, n.shape[2], n.shape[3], dev) for n in (n0, n1, n2)]
+        self.err = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.fuse_gru = FUSE_GRU
         self.graph = None
 
     @staticmethod
@@ -85,9 +93,20 @@ class C8Loop:
         z = c8.gate_zr([self.hc8[lvl], *xs], gru._merged_zr(), cz, cr, h, rh_c8=self.rh[lvl], cfg=cfg_zr)
         c8.gate_out([self.rh[lvl], *xs], gru.convq, cq, z, h, h, out_c8=self.hc8[lvl], cfg=cfg_q)
 
+    def _gru_desc(self, lvl, gru, st, xs):
+        cz, cr, cq = st["inp"][lvl]
+        return c8.gru_desc(gru, self.hc8[lvl], xs, self.rh[lvl], cz, cr, cq, st["net"][lvl], self.gflags[lvl])
+
     def _gru_pair(self, st):
-        """gru08 of this iteration and gru32 of the next one in two shared launches."""
+        """gru08 of this iteration and gru32 of the next one: ONE launch (csrc/gru_c8.hip), or two shared launches
+        (z|r + gates, q + state update) where the fused form does not apply."""
         fine, _, coarse = self.grus
+        if self.fuse_gru:
+            d0 = self._gru_desc(0, fine, st, [self.mf, self.up1])
+            d1 = self._gru_desc(2, coarse, st, [self.pool1])
+            if c8.gru_launch(d0, d1, err=self.err):
+                return
+            self.fuse_gru = False          # this device / shape cannot hold the launch: the two-launch form from here on
         ds = []
         zs = []
         for lvl, gru, xs in ((0, fine, [self.mf, self.up1]), (2, coarse, [self.pool1])):

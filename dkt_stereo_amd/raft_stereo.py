@@ -632,6 +632,10 @@ class RAFTStereo(nn.Module):
             fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
             flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
             finite = (not self.check_finite) or bool(torch.isfinite(flow_up).all())
+            lp = (self._graph_state or {}).get("c8") if self.check_finite else None
+            if lp is not None and int(lp.err.item()):
+                raise _ffi.DktError("the fused ConvGRU launch timed out waiting for a neighbour tile (csrc/gru_c8.hip): "
+                                    "the device did not keep the launch's blocks resident; set DKT_C8_FUSE_GRU=0")
         if not finite:
             raise _ffi.DktError(
                 "RAFTStereo.forward produced non-finite disparities: an activation left the range of the "

@@ -471,6 +471,38 @@ int dkt_head_finish(const float *planes, long planes_bstride, int n_co, const fl
 /* two independent convolutions in one launch (the coarsest GRU rides with the finest); cfg != 0 */
 int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_desc *d1, int cfg, int device, void *stream);
 
+/* Round 4: one whole ConvGRU step (core/update.py:23-32 == meta_arch/igev_stereo/update.py:32-41) in ONE launch on C8S
+ * operands (csrc/gru_c8.hip):
+ *     z = sigmoid(convz([h, x]) + cz);  r = sigmoid(convr([h, x]) + cr);
+ *     q = tanh(convq([r*h, x]) + cq);   h <- (1 - z) h + z q          (fp32 NCHW `h` and its C8S twin `h_c8`, both in place)
+ * z never leaves the registers; r*h goes through the C8S scratch `rh_c8`; the q convolution of a tile waits for the
+ * flags of its 3x3 neighbour tiles instead of a kernel boundary.  hidden must be 128.
+ *   w_zr : dkt_conv_c8_pack_weights image of the 256-output layer whose output channel 64*k + 32*m + i is
+ *          (m == 0 ? convz : convr) channel 32*k + i, input channels in the reference's order [h | x...];
+ *   w_q  : image of convq with its input channels REORDERED to [x... | r*h] (the x chunks are consumed first);
+ *   bz, br, bq : the three biases in the reference's channel order;  scale_* : 1 / (weight scale * activation scale);
+ *   flags : dkt_gru_c8_flag_words(B, H, W) zero-initialised 32-bit words owned by this (operator, shape) pair -- every
+ *           launch increments them, they must not be shared with a launch of another shape or written by the caller;
+ *   err_word (optional, device memory): set to 1 if a neighbour wait timed out (results are then invalid).
+ * DKT_E_UNSUPPORTED when the device cannot hold the launch's tiles the way the flags need (fall back to two
+ * dkt_conv2d_c8 launches with epilogues 1 and 2). */
+typedef struct dkt_gru_c8_desc {
+    void *h_c8; long h_c8_bstride;              /* C8S hidden state (hidden channels), bytes per batch item */
+    const void *x[3]; long x_bstride[3]; int x_channels[3]; int nx;   /* the reference's x_list as C8S tensors */
+    void *rh_c8; long rh_c8_bstride;            /* C8S scratch for r*h (zero border, as every C8S tensor) */
+    const void *w_zr, *w_q;
+    const float *bz, *br, *bq;
+    const float *cz, *cr, *cq; long cz_bstride, cr_bstride, cq_bstride;   /* context terms, fp32 NCHW, strides in floats */
+    float *h; long h_bstride;                   /* fp32 NCHW hidden state */
+    float scale_zr, scale_q, act_scale;
+    int B, H, W, hidden;
+    unsigned *flags;
+} dkt_gru_c8_desc;
+long dkt_gru_c8_flag_words(int B, int H, int W);
+int dkt_gru_c8(const dkt_gru_c8_desc *d, unsigned *err_word, int device, void *stream);
+/* two independent ConvGRU steps (the finest level and the coarsest one of the next iteration) in one launch */
+int dkt_gru_c8_pair(const dkt_gru_c8_desc *d0, const dkt_gru_c8_desc *d1, unsigned *err_word, int device, void *stream);
+
 /* Producers of C8S operands besides the convolution epilogues (same arithmetic as their fp32 twins):
  *   dkt_pool2x_c8 / dkt_interp_c8 : pool2x / interp of core/update.py:87-95, fp32 NCHW in (B,C,H,W);
  *   dkt_conv2d_stem7_c8           : the 7x7 stem (convf1, core/update.py:75);

@@ -1,0 +1,173 @@
+"""-m gpu: round 4 -- one ConvGRU step per launch (csrc/gru_c8.hip, core/update.py:23-32).
+
+Oracles: torch's fp64 ConvGRU arithmetic on the same operands (bound 4e-6 relative: the split-fp16 class, with the context
+terms as the accumulators' start value), the two-launch form of round 3 (conv_c8 epilogues 1 + 2: the same arithmetic in
+another summation order) and, through the full model, the reference fixtures (tests/test_gpu_round3.py runs the loop that
+now takes this launch).  The inter-tile hand-off (write-through r*h, per-tile flags, one agent acquire) is exercised with
+batches that give every block several tiles, launch after launch on the same flag words, and must be bit-reproducible.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_parity import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def _c8():
+    from dkt_stereo_amd import conv_c8
+    return conv_c8
+
+
+def _make(B, H, W, xch, seed, ctx_scale=1.0):
+    from dkt_stereo_amd.update import ConvGRU
+    torch.manual_seed(seed)
+    gru = ConvGRU(128, sum(xch)).to(DEV)
+    h = torch.tanh(torch.randn(B, 128, H, W, device=DEV))
+    xs = [torch.randn(B, c, H, W, device=DEV) for c in xch]
+    cz, cr, cq = (torch.randn(B, 128, H, W, device=DEV) * ctx_scale for _ in range(3))
+    return gru, h, xs, cz, cr, cq
+
+
+def _ref64(gru, h, xs, cz, cr, cq):
+    """core/update.py:23-32 in fp64."""
+    p = {k: v.double() for k, v in gru.state_dict().items()}
+    h, cz, cr, cq = h.double(), cz.double(), cr.double(), cq.double()
+    x = torch.cat([t.double() for t in xs], 1)
+    hx = torch.cat([h, x], 1)
+    z = torch.sigmoid(F.conv2d(hx, p["convz.weight"], p["convz.bias"], padding=1) + cz)
+    r = torch.sigmoid(F.conv2d(hx, p["convr.weight"], p["convr.bias"], padding=1) + cr)
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), p["convq.weight"], p["convq.bias"], padding=1) + cq)
+    return (1 - z) * h + z * q
+
+
+class _State:
+    def __init__(self, gru, h, xs, cz, cr, cq):
+        c8 = _c8()
+        B, _, H, W = h.shape
+        self.gru, self.h, self.cz, self.cr, self.cq = gru, h.clone(), cz, cr, cq
+        self.hc8 = c8.pack(self.h)
+        self.xs = [c8.pack(x) for x in xs]
+        self.rh = c8.ActC8(B, 128, H, W, DEV)
+        self.flags = c8.gru_flags(B, H, W, DEV)
+
+    def desc(self):
+        return _c8().gru_desc(self.gru, self.hc8, self.xs, self.rh, self.cz, self.cr, self.cq, self.h, self.flags)
+
+    def two_launch(self):
+        c8 = _c8()
+        z = c8.gate_zr([self.hc8, *self.xs], self.gru._merged_zr(), self.cz, self.cr, self.h, rh_c8=self.rh, cfg=1)
+        c8.gate_out([self.rh, *self.xs], self.gru.convq, self.cq, z, self.h, self.h, out_c8=self.hc8, cfg=2)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("B,H,W,xch", [(1, 96, 160, [128, 128]),      # 60 tiles, one per block
+                                       (1, 23, 39, [128]),            # the coarsest GRU of cfg2: 6 tiles, ragged on both axes
+                                       (1, 50, 70, [64, 40, 24]),     # three operands, channel counts that pad to 16
+                                       (2, 184, 312, [128, 128]),     # 460 tiles on 256 CUs: two tiles per block, neighbours across rounds
+                                       (5, 96, 160, [128])])          # 300 tiles
+def test_fused_gru_step_matches_fp64_and_the_two_launch_form(B, H, W, xch):
+    c8 = _c8()
+    args = _make(B, H, W, xch, seed=B * 1000 + H)
+    a, b = _State(*args), _State(*args)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    h_ref = args[1]
+    for step in range(3):                        # the same flag words launch after launch; the state evolves
+        want = _ref64(args[0], h_ref, *args[2:])
+        assert c8.gru_launch(a.desc(), err=err), "the device declined a launch it must be able to hold"
+        b.two_launch()
+        assert _rel(a.h, want) <= 4e-6 and _rel(b.h, want) <= 4e-6, (step, _rel(a.h, want), _rel(b.h, want))
+        # the C8S twin is the split of the fp32 state; border and padding stay zero
+        assert torch.equal(a.hc8.t, c8.pack(a.h).t)
+        assert float(a.hc8.t[:, :, :, 0].abs().max()) == 0 and float(a.hc8.t[:, :, :, :, 0].abs().max()) == 0
+        assert float(a.rh.t[:, :, :, H + 1:].abs().max()) == 0 and float(a.rh.t[:, :, :, :, W + 1:].abs().max()) == 0
+        h_ref = want.float()
+        a.h.copy_(h_ref); b.h.copy_(h_ref)       # both forms continue from the oracle's state
+        c8.pack(a.h, a.hc8); c8.pack(b.h, b.hc8)
+    assert int(err.item()) == 0
+    assert int(a.flags.min()) == 3 and int(a.flags.max()) == 3
+
+
+@torch.no_grad()
+def test_fused_gru_pair_equals_single_launches_and_is_reproducible():
+    """Two ConvGRU steps in one launch (the finest level with the coarsest riding along, as the loop issues them) are
+    bit-identical to the two single launches; twelve launches from the same state give one result."""
+    c8 = _c8()
+    big, small = _make(1, 184, 312, [128, 128], 11), _make(1, 23, 39, [128], 12)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    sa, sb = _State(*big), _State(*small)
+    assert c8.gru_launch(sa.desc(), sb.desc(), err=err)
+    ra, rb = _State(*big), _State(*small)
+    assert c8.gru_launch(ra.desc(), err=err) and c8.gru_launch(rb.desc(), err=err)
+    assert torch.equal(sa.h, ra.h) and torch.equal(sb.h, rb.h) and torch.equal(sa.hc8.t, ra.hc8.t) and torch.equal(sb.hc8.t, rb.hc8.t)
+    for _ in range(12):
+        ta, tb = _State(*big), _State(*small)
+        c8.gru_launch(ta.desc(), tb.desc(), err=err)
+        assert torch.equal(ta.h, sa.h) and torch.equal(tb.h, sb.h) and torch.equal(ta.rh.t, sa.rh.t)
+    assert int(err.item()) == 0
+
+
+@torch.no_grad()
+def test_fused_gru_hand_off_under_uneven_load():
+    """The neighbour hand-off with the device busy elsewhere: a streaming kernel on a second stream keeps some CUs' memory
+    queues loaded while 40 dependent steps run; every step must equal the undisturbed run bit for bit (a stale r*h halo or
+    an early state update would change the result)."""
+    c8 = _c8()
+    args = _make(2, 184, 312, [128, 128], 21)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    quiet = _State(*args)
+    want = []
+    for _ in range(40):
+        c8.gru_launch(quiet.desc(), err=err)
+        want.append(quiet.h.clone())
+    torch.cuda.synchronize()
+    noisy = _State(*args)
+    side = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device=DEV)
+    stop = torch.cuda.Event()
+    got = []
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            junk.mul_(1.0001)
+        stop.record()
+    for _ in range(40):
+        c8.gru_launch(noisy.desc(), err=err)
+        got.append(noisy.h.clone())
+    stop.synchronize()
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
+    assert int(err.item()) == 0
+
+
+@torch.no_grad()
+def test_fused_gru_context_terms_of_any_size():
+    """The accumulators start at (bias + context) / scale: large and tiny context terms keep the fp64 bound."""
+    c8 = _c8()
+    for scale in (1e-3, 30.0):
+        args = _make(1, 48, 96, [128], 31, ctx_scale=scale)
+        s = _State(*args)
+        assert c8.gru_launch(s.desc())
+        assert _rel(s.h, _ref64(*args)) <= 4e-6
+
+
+@torch.no_grad()
+def test_fused_gru_argument_errors():
+    import ctypes
+    c8 = _c8()
+    from dkt_stereo_amd import _ffi
+    args = _make(1, 32, 64, [128], 41)
+    s = _State(*args)
+    d = s.desc()
+    d.hidden = 96
+    assert _ffi.lib().dkt_gru_c8(ctypes.byref(d), None, 0, None) == _ffi.E_UNSUPPORTED
+    d = s.desc()
+    d.flags = None
+    assert _ffi.lib().dkt_gru_c8(ctypes.byref(d), None, 0, None) < 0
+    with pytest.raises(ValueError):
+        c8.gru_desc(s.gru, s.hc8, s.xs, c8.ActC8(1, 128, 16, 64, DEV), s.cz, s.cr, s.cq, s.h, s.flags)
