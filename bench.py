@@ -59,6 +59,8 @@ def parse():
                    help="pairs per GPU per step (default 1; with --gpus > 1: 8 = BASELINE.json configs[3], batch 64 over 8 GPUs)")
     p.add_argument("--cpu-iters", type=int, default=6, help="GRU iterations timed by the CPU baseline sample")
     p.add_argument("--skip-cpu-baseline", action="store_true")
+    p.add_argument("--pmc", action="store_true",
+                   help="measure roofline.traffic in this run: two rocprofv3 --pmc sub-runs (FETCH_SIZE, WRITE_SIZE) of the reported launches")
     p.add_argument("--conv-backend", default=None, choices=["f16x3", "f16x2", "f16", "miopen"],
                    help="update-block convolution path (default: the package default, f16x3)")
     a = p.parse_args()
@@ -91,6 +93,39 @@ class TimedCorr:
         b.record()
         self.sink.append((a, b))
         return out
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per launch of the two reported kernels, measured now: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
+    in SEPARATE sub-runs (kernel trace only) of tools/pmc/pmc_probe_r04.py, which launches the same kernels on the same
+    shapes plus a known-traffic calibration stream; reads are FETCH_SIZE x the correction that stream yields."""
+    import subprocess
+    script = os.path.join(ROOT, "tools", "pmc", "run_pmc_r04.sh")
+    try:
+        subprocess.run(["bash", script], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        with open(os.path.join(ROOT, "gpurun_out", "r04_pmc", "traffic.json")) as f:
+            j = json.load(f)
+        return {"conv_bytes": j.get("gru_bytes"), "lookup_bytes": j.get("lookup_conv1x1_b1_bytes"),
+                "note": "measured in this run: %s" % j.get("source")}
+    except Exception as e:          # counters unavailable on this box: say so, report nothing
+        return {"note": "--pmc failed: %s" % (str(e)[:200],)}
+
+
+def conv_precision(dev):
+    """Relative error of the path's convolution arithmetic against an fp64 convolution of the same operands, measured now
+    (3x3, 128 -> 128, 96x160, standard-normal operands) -- what "22-bit operands" buys on this device."""
+    import torch.nn.functional as F
+    from dkt_stereo_amd import conv as _conv
+    torch.manual_seed(5)
+    layer = torch.nn.Conv2d(128, 128, 3, padding=1).to(dev)
+    x = torch.randn(1, 128, 96, 160, device=dev)
+    with torch.no_grad():
+        want = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=1)
+        got = {"round-2 kernel (encoders)": _conv.conv2d(x, layer)}
+        if _conv.get_backend() == "f16x3":
+            from dkt_stereo_amd import conv_c8
+            got["C8S kernel (refinement loop)"] = conv_c8.conv2d_c8([conv_c8.pack(x)], layer)
+        return {k: float((v.double() - want).abs().max() / want.abs().max()) for k, v in got.items()}
 
 
 def cpu_baseline(args, sd, cfg, i1, i2):
@@ -353,6 +388,11 @@ def main():
         torch.cuda.synchronize()
         hot_ms = e0.elapsed_time(e1)
 
+    precision = {"operand_bits": {"f16x3": 22, "f16x2": 11, "f16": 11, "miopen": 24}[_conv.get_backend()],
+                 "accumulate": "fp32",
+                 "conv_rel_err_vs_fp64": conv_precision(dev),
+                 "vendor_fp32_conv_rel_err_vs_fp64": 0.9e-6,
+                 "bound": "final disparity <= 1e-3 max-abs of the reference (north_star); see max_abs_vs_reference"}
     n_pix = B * h4 * w4
     look_avg_ms = sum(look_ms) / max(len(look_ms), 1)
     alg = lookup_bytes_per_launch(n_pix, cout=64 if fused_lookup else None)
@@ -389,6 +429,7 @@ def main():
     except (OSError, ValueError):
         pass
     default_shape = (args.height, args.width, B) == (736, 1248, 1)
+    live_traffic = pmc_traffic(args) if (args.pmc and default_shape) else {}
     out = {
         "metric": "stereo pairs/sec at 736x1248 D=192, 32 iters (RAFT-Stereo test_mode forward)",
         "value": world * B * args.steps / elapsed,
@@ -405,7 +446,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        # the arithmetic type of the path, not a precision claim: tensors and accumulation are fp32, every product of the
+        # convolutions is evaluated on the fp16 matrix pipe from split operands (see "precision")
+        "dtype": {"f16x3": "f32 io/accumulate; convolution products = 3x fp16-split MFMA (22-bit operands); lookup / correlation exact fp32",
+                  "f16x2": "f32 io/accumulate; convolution products = 2x fp16-split MFMA (NOT a parity path)",
+                  "f16": "f32 io/accumulate; convolution products = fp16 MFMA (NOT a parity path)",
+                  "miopen": "f32 (vendor fp32 convolutions)"}[_conv.get_backend()],
+        "precision": precision,
         "data": "synthetic (seeded U[0,255) left image, shifted+noised right image; random-init weights)",
         "config": {"workload": "RAFT-Stereo %dx%d (1/4 res %dx%d), D=192, %d GRU iters, batch %d/GPU, "
                                "corr_implementation=reg, BASELINE.json configs[1]"
@@ -433,11 +480,14 @@ def main():
                      "frac_algorithmic": conv_tflops_exec / passes / FP16_MFMA_PEAK_TFLOPS,
                      "mfma_issue_frac": conv_tflops_exec / FP16_MFMA_PEAK_TFLOPS,
                      "mfma_issued_tflops": conv_tflops_exec,
-                     "frac_of_fp32_mfma_peak": conv_tflops_exec / passes / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic.get("conv_zr_gate_bytes") if default_shape else None,
-                     "traffic_source": traffic.get("source") if default_shape else None,
+                     # HBM-side bytes per launch: measured in THIS run only with --pmc (two rocprofv3 --pmc sub-runs of the same
+                     # launch); otherwise null, and the builder's committed passes are quoted under their own key
+                     "traffic": live_traffic.get("conv_bytes"),
+                     "traffic_note": live_traffic.get("note", "not measured in this run (pass --pmc)"),
+                     "traffic_from_profiles": ({"bytes": traffic.get("gru_bytes" if gru_used else "conv_zr_gate_bytes"),
+                                                "source": "%s -- NOT this run" % traffic.get("source")}
+                                               if default_shape and traffic else None),
                      "algorithmic_flops_per_launch": conv_alg_flops, "mfma_passes": passes,
-                     "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
         # the kernel BASELINE.json's north_star sets the HBM target for
@@ -446,14 +496,18 @@ def main():
                             else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": traffic.get("lookup_conv1x1_b1_bytes" if fused_lookup else "lookup_b1_bytes") if default_shape else None,
-                            "traffic_source": traffic.get("source") if default_shape else None,
+                            "traffic": live_traffic.get("lookup_bytes"),
+                            "traffic_note": live_traffic.get("note", "not measured in this run (pass --pmc)"),
+                            "traffic_from_profiles": ({"bytes": traffic.get("lookup_conv1x1_b1_bytes" if fused_lookup else "lookup_b1_bytes"),
+                                                       "source": "%s -- NOT this run" % traffic.get("source")}
+                                                      if default_shape and traffic else None),
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
                             "launches_timed": len(look_ms),
                             # the same kernel as the loop runs it (rocprofv3 kernel trace of this command, kept under profiles/)
-                            "in_pipeline_avg_launch_us": traffic.get("lookup_in_pipeline_us") if default_shape else None,
-                            "in_pipeline_frac": (alg / (traffic["lookup_in_pipeline_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
-                            if default_shape and traffic.get("lookup_in_pipeline_us") else None},
+                            "in_pipeline_from_profiles": ({"avg_launch_us": traffic.get("lookup_in_pipeline_us"),
+                                                           "frac": alg / (traffic["lookup_in_pipeline_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                           "source": "%s -- NOT this run" % traffic.get("lookup_in_pipeline_source")}
+                                                          if default_shape and traffic.get("lookup_in_pipeline_us") else None)},
     }
     # EPE against the reference itself (BASELINE.json's "EPE vs ref"): tests/golden/raft_e2e.npz holds the
     # reference's CPU output for this exact workload (seed 3, shift 40, 32 iterations, every 8th pixel)

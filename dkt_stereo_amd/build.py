@@ -14,17 +14,20 @@ LIB = os.path.join(LIB_DIR, "libdktstereo.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
           "-ffp-contract=off",  # the sampler arithmetic is reproduced bit for bit
+          # NO packed fp32 math anywhere: the SLP vectoriser turns neighbouring scalar fp32 operations into
+          # v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, and conv3x3_few_kernel's packed accumulators came back wrong (low
+          # halves, lanes 48..63) whenever its block shared a CU with a block of an MFMA kernel -- 1000 of 1200 launches,
+          # 0 of 1200 with scalar math.  The mechanism is not reproducible in isolation, so the rule is library-wide and
+          # check_no_packed_fp32() below enforces it on the linked code objects.
+          "-fno-slp-vectorize", "-fno-vectorize",      # (the loop vectoriser packs pairs of iterations the same way)
           "-Wno-pass-failed"]
 FLAGS = CFLAGS + ["-shared"]       # single-command form: hipcc FLAGS csrc/*.hip -o libdktstereo.so
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
-# Per-source flags.  conv_direct: no SLP vectorisation, i.e. scalar v_fma_f32 instead of v_pk_fma_f32 chains -- the
-# SLP build of conv3x3_few_kernel returned wrong low halves of its packed accumulators (lanes 48..63) whenever its
-# block shared a CU with a block of the MFMA convolution (tools/stress_lds_dma.py: 1000/1200 launches wrong
-# with packed math, 0/1200 with scalar math under the same co-residency).
+# Per-source flags.
 # conv_c8: its step and epilogue are fully unrolled by construction (accumulators and fragments must stay in registers: a loop
 # the unroller gives up on indexes them dynamically and sends the 128 accumulators to scratch -- 540 us instead of 280);
 # the epilogue's body exceeds the default threshold of `#pragma unroll`.
-EXTRA_FLAGS = {"conv_direct": ["-fno-slp-vectorize"], "conv_c8": ["-mllvm", "-pragma-unroll-threshold=100000"],
+EXTRA_FLAGS = {"conv_c8": ["-mllvm", "-pragma-unroll-threshold=100000"],
                "gru_c8": ["-mllvm", "-pragma-unroll-threshold=100000"]}
 
 
@@ -79,7 +82,50 @@ def build(force=False, verbose=False):
         sys.stderr.write(res.stdout)
         raise RuntimeError("hipcc failed linking libdktstereo.so")
     _assert_product_build()
+    bad = check_no_packed_fp32([obj for (_, obj, _), _ in results])
+    if bad:
+        raise RuntimeError("packed fp32 math in device code (DESIGN 3.4 forbids it):\n  " +
+                           "\n  ".join("%s: %d x %s" % (k, n, op) for k, op, n in bad[:20]))
     return LIB
+
+
+PACKED_FP32 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+
+
+def check_no_packed_fp32(objects):
+    """Disassembles the gfx950 code object of every compiled source and returns [(kernel, opcode, count)] for every
+    packed fp32 arithmetic instruction found (empty = the rule of DESIGN 3.4 holds).  Skipped (returns []) when
+    llvm-objdump is unavailable."""
+    import collections
+    import re
+    import shutil
+    import tempfile
+    if not os.path.exists(OBJDUMP):
+        return []
+    found = collections.Counter()
+    tmp = tempfile.mkdtemp(prefix="dkt_pk_")
+    try:
+        for obj in objects:
+            local = os.path.join(tmp, os.path.basename(obj))
+            shutil.copy(obj, local)
+            subprocess.run([OBJDUMP, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)
+            for f in sorted(os.listdir(tmp)):
+                if not f.startswith(os.path.basename(obj) + ".") or "gfx950" not in f:
+                    continue
+                dis = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+                kernel = "?"
+                for line in dis.splitlines():
+                    m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+                    if m:
+                        kernel = m.group(1)
+                        continue
+                    for op in PACKED_FP32:
+                        if op in line:
+                            found[(kernel, op)] += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return sorted((k, op, n) for (k, op), n in found.items())
 
 
 def _assert_product_build():

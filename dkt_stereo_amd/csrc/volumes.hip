@@ -60,12 +60,8 @@ __global__ __launch_bounds__(256) void gwc_volume_kernel(const float *__restrict
 // of them busy at W = 312 and issued one scalar store per output), the footprint is ~60 registers (8 waves
 // per SIMD hide the LDS and store latency), and the sum stays the reference's: s = s + r_j * t_j over the group's channels in
 // ascending order, products rounded before they are added, mean by the same division.  Bit-identical.
-typedef float gwc_f2 __attribute__((ext_vector_type(2)));
 typedef float gwc_f4 __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) gwc_f4 *gwc_lds_f4p;
-#ifndef GWC_ABL
-#define GWC_ABL 0      // timing-only ablations: 1 = no global loads, 2 = no compute (LDS reads + math), 4 = no stores
-#endif
 template <bool VEC>
 __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__restrict__ ref,
                                                               const float *__restrict__ tgt,
@@ -93,12 +89,8 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
                     // clamped (always valid) addresses: the loads stay unconditional, so all 16 are in flight at once
                     const int j = min(j0 + 4 * k, cpg - 1), wq = min(ln + 64 * q, nq4 - 1);
                     const size_t o = chan0 + (size_t)j * HW + 4 * wq;
-                    if (GWC_ABL & 1) {
-                        v[k][q] = u[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    } else {
-                        v[k][q] = *(const float4 *)(tgt + o);
-                        u[k][q] = *(const float4 *)(ref + o);
-                    }
+                    v[k][q] = *(const float4 *)(tgt + o);
+                    u[k][q] = *(const float4 *)(ref + o);
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -127,8 +119,8 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
         for (int k = 0; k < 4; ++k) {
             const int i = i0 + 256 * k;
             const int j = i / W, w = i - j * W;
-            v[k] = (i < n_el && !(GWC_ABL & 1)) ? tgt[chan0 + (size_t)j * HW + w] : 0.0f;
-            u[k] = (i < n_el && !(GWC_ABL & 1)) ? ref[chan0 + (size_t)j * HW + w] : 0.0f;
+            v[k] = (i < n_el) ? tgt[chan0 + (size_t)j * HW + w] : 0.0f;
+            u[k] = (i < n_el) ? ref[chan0 + (size_t)j * HW + w] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -155,11 +147,11 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
         // ALIGNED quads starting at w - d0 - 4 (w, d0, lpad multiples of 4) -> t8[0..7], column c at t8[c - (w-d0-4)]
         const float *tp = gwc_lds + lpad + w - d0 - 4;               // >= gwc_lds: d0 + 4 <= lpad
         const float *rp = rlds + w;
-        gwc_f2 s[4][2];
+        float s[4][4];
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) s[dd][0] = s[dd][1] = gwc_f2{0.0f, 0.0f};
+        for (int dd = 0; dd < 4; ++dd) s[dd][0] = s[dd][1] = s[dd][2] = s[dd][3] = 0.0f;
 #pragma unroll 4
-        for (int j = 0; j < ((GWC_ABL & 2) ? 1 : cpg); ++j) {
+        for (int j = 0; j < cpg; ++j) {
             // every term of these addresses is a multiple of 4 floats: tell the compiler (ds_read_b128, not 2 x ds_read2_b32)
             const float4 rq = *(const float4 *)__builtin_assume_aligned(rp + j * rpitch, 16);    // (entries past W feed unstored outputs only)
             // (volatile: the compiler would otherwise narrow the two quads to the 7 floats used and read them as 4 pieces)
@@ -167,24 +159,22 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_kernel(const float *__res
             gwc_lds_f4p tq = (gwc_lds_f4p)(tp + j * pitch);
             const gwc_f4 ta = tq[0], tb = tq[1];
             const float t8[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-            const gwc_f2 r01{rq.x, rq.y}, r23{rq.z, rq.w};
-            // packed fp32: v_pk_mul_f32 then v_pk_add_f32 (never fused: the reference rounds the product first)
+            const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
+            // scalar multiply then add (never fused: the reference rounds the product first; never packed: DESIGN 3.4)
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                s[dd][0] = s[dd][0] + r01 * gwc_f2{t8[4 - dd], t8[5 - dd]};
-                s[dd][1] = s[dd][1] + r23 * gwc_f2{t8[6 - dd], t8[7 - dd]};
-            }
+            for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[dd][i] = __fadd_rn(s[dd][i], __fmul_rn(rv[i], t8[4 - dd + i]));
         }
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
             const int d = d0 + dd;
             if (d >= D) break;
-            const float sv[4] = {s[dd][0].x, s[dd][0].y, s[dd][1].x, s[dd][1].y};
+            const float sv[4] = {s[dd][0], s[dd][1], s[dd][2], s[dd][3]};
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = (w + i >= d) ? (pow2 ? __fmul_rn(sv[i], rcp) : __fdiv_rn(sv[i], fcpg)) : 0.0f;
             float *dst = vrow + (size_t)d * HW + w;
-            if ((GWC_ABL & 4) && o[0] != 12345.0f) continue;
             if (VEC && w + 3 < W) {
                 *(float4 *)dst = make_float4(o[0], o[1], o[2], o[3]);
             } else {
@@ -217,11 +207,11 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_chunked_kernel(const floa
     float *rlds = gwc_lds + GWC_CH * pitch;
     const int nq4 = W >> 2, wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     const int nq = nq4, ndq = (D + 3) / 4;
-    gwc_f2 s[GWC_NI][4][2];
+    float s[GWC_NI][4][4];
 #pragma unroll
     for (int i = 0; i < GWC_NI; ++i)
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) s[i][dd][0] = s[i][dd][1] = gwc_f2{0.0f, 0.0f};
+        for (int dd = 0; dd < 4; ++dd) s[i][dd][0] = s[i][dd][1] = s[i][dd][2] = s[i][dd][3] = 0.0f;
     int iw[GWC_NI], id0[GWC_NI];
     bool iok[GWC_NI];
 #pragma unroll
@@ -276,12 +266,11 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_chunked_kernel(const floa
                 gwc_lds_f4p tq = (gwc_lds_f4p)(tp + j * pitch);
                 const gwc_f4 ta = tq[0], tb = tq[1];
                 const float t8[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-                const gwc_f2 r01{rq.x, rq.y}, r23{rq.z, rq.w};
+                const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
 #pragma unroll
-                for (int dd = 0; dd < 4; ++dd) {
-                    s[i][dd][0] = s[i][dd][0] + r01 * gwc_f2{t8[4 - dd], t8[5 - dd]};
-                    s[i][dd][1] = s[i][dd][1] + r23 * gwc_f2{t8[6 - dd], t8[7 - dd]};
-                }
+                for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[i][dd][e] = __fadd_rn(s[i][dd][e], __fmul_rn(rv[e], t8[4 - dd + e]));
             }
         }
     }
@@ -297,7 +286,7 @@ __global__ __launch_bounds__(256) void gwc_volume_quad_chunked_kernel(const floa
         for (int dd = 0; dd < 4; ++dd) {
             const int d = id0[i] + dd;
             if (d >= D) break;
-            const float sv[4] = {s[i][dd][0].x, s[i][dd][0].y, s[i][dd][1].x, s[i][dd][1].y};
+            const float sv[4] = {s[i][dd][0], s[i][dd][1], s[i][dd][2], s[i][dd][3]};
             float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = (w + k >= d) ? (pow2 ? __fmul_rn(sv[k], rcp) : __fdiv_rn(sv[k], fcpg)) : 0.0f;

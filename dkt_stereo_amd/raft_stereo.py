@@ -617,13 +617,20 @@ class RAFTStereo(nn.Module):
             delta_flow = torch.cat([delta_flow[:, :1], torch.zeros_like(delta_flow[:, 1:])], dim=1)
             coords1 = coords1 + delta_flow
             predictions.append(self.upsample_flow(coords1 - coords0, up_mask)[:, :1])
-        return predictions
+        # the reference's return convention (raft_stereo.py:185-187): its loss reads results['disp_preds'] (loss.py:5,
+        # tools/ft_dkt.py:218,262)
+        return dict(disp_preds=predictions)
 
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False):
         if not test_mode:
-            # the reference's default: the list of every iteration's prediction (differentiable when autograd is enabled;
+            # the reference's default: {'disp_preds': every iteration's prediction} (differentiable when autograd is enabled;
             # under torch.no_grad() the same loop on the inference kernels, without the captured-graph fast path)
-            return self._forward_train(image1, image2, iters, flow_init)
+            with GPU_GUARD.shared():          # (kernel launches of this thread vs another thread's graph capture)
+                out = self._forward_train(image1, image2, iters, flow_init)
+                finite = (not self.check_finite) or bool(torch.isfinite(out["disp_preds"][-1]).all())
+            if not finite:
+                raise _ffi.DktError("RAFTStereo.forward(test_mode=False) produced non-finite disparities")
+            return out
         with torch.no_grad():
             return self._forward_test(image1, image2, iters, flow_init)
 

@@ -499,12 +499,14 @@ def test_raft_training_forward_matches_inference_and_oracle_gradients():
     g1, g2 = G(i1), G(i2)
     with torch.no_grad():
         _, want_up = model(g1, g2, iters=3, test_mode=True)
-    preds = model(g1, g2, iters=3, test_mode=False)
+    out = model(g1, g2, iters=3, test_mode=False)
+    assert isinstance(out, dict) and list(out) == ["disp_preds"]          # the reference's convention (raft_stereo.py:185-187)
+    preds = out["disp_preds"]
     assert len(preds) == 3 and preds[-1].requires_grad
     assert maxabs(preds[-1].detach(), want_up) <= 1e-4
     wl = torch.randn(1, 1, 64, 128, generator=torch.Generator().manual_seed(9))
     params = dict(model.named_parameters())
-    pred = model(g1, g2, iters=1, test_mode=False)[0]
+    pred = model(g1, g2, iters=1, test_mode=False)["disp_preds"][0]
     got = torch.autograd.grad((pred * wl.to(DEV)).sum(), [params[n] for n in names])
     sdd = {k: v.clone() for k, v in sd.items()}
     for n in names:
@@ -516,7 +518,7 @@ def test_raft_training_forward_matches_inference_and_oracle_gradients():
     for n, a, b in zip(names, got, want):
         assert _rel(a.cpu(), b) <= 5e-4, (n, _rel(a.cpu(), b))
     with torch.no_grad():        # the reference's call convention without autograd: the same list, on the inference kernels
-        plain = model(g1, g2, iters=3, test_mode=False)
+        plain = model(g1, g2, iters=3, test_mode=False)["disp_preds"]
     assert len(plain) == 3 and not plain[-1].requires_grad and maxabs(plain[-1], want_up) <= 1e-4
 
 
