@@ -45,7 +45,7 @@ class ConvC8Desc(ctypes.Structure):
                 ("out2_c8", ctypes.c_void_p), ("out2_c8_bstride", ctypes.c_long), ("out2_c8_ch0", ctypes.c_int),
                 ("tail", ctypes.c_void_p), ("tail_bstride", ctypes.c_long), ("tail_channels", ctypes.c_int),
                 ("head_w", ctypes.c_void_p), ("head_out", ctypes.c_void_p), ("head_out_bstride", ctypes.c_long),
-                ("head_outputs", ctypes.c_int), ("f32_c4", ctypes.c_int)]
+                ("head_outputs", ctypes.c_int), ("f32_c4", ctypes.c_int), ("tail_scale", ctypes.c_float)]
 
 
 class GruC8Desc(ctypes.Structure):

@@ -18,13 +18,37 @@ def c8_dims(H, W):
 
 
 class ActC8:
-    """A C8S activation tensor.  ``t``: fp16 storage (B, G, 2, Hp, Wp, 8), zero outside the written interior."""
-    __slots__ = ("t", "C", "H", "W", "scale")
+    """A C8S activation tensor.  ``t``: fp16 storage (B, G, 2, Hp, Wp, 8), zero outside the written interior.
+    ``scale``: the power of two its values are multiplied by before the fp16 (hi, lo) split -- the format keeps 22 significant
+    bits only while |x * scale| sits in fp16's normal range, so producers scale and consumers fold 1 / scale into their packed
+    weights (`channel_scales`); ``tail`` trailing channels (flow / disparity next to features, core/update.py:85) may carry a
+    scale of their own (``tail_scale``).  loop_c8.C8Loop.calibrate picks the scales from observed magnitudes."""
+    __slots__ = ("t", "C", "H", "W", "scale", "tail", "tail_scale")
 
-    def __init__(self, B, C, H, W, device, scale=1.0):
+    def __init__(self, B, C, H, W, device, scale=1.0, tail=0):
         Hp, Wp = c8_dims(H, W)
         self.t = torch.zeros((B, 2 * ((C + 15) // 16), 2, Hp, Wp, 8), device=device, dtype=torch.float16)
         self.C, self.H, self.W, self.scale = C, H, W, float(scale)
+        self.tail, self.tail_scale = int(tail), float(scale)
+
+    def channel_scales(self):
+        """((channels, scale), ...) segments in channel order."""
+        if self.tail and self.tail_scale != self.scale:
+            return ((self.C - self.tail, self.scale), (self.tail, self.tail_scale))
+        return ((self.C, self.scale),)
+
+    def absmax(self):
+        """(max |x * scale| over the body channels, max |x * tail_scale| over the tail channels) as 0-dim fp32 tensors: what
+        the hi halves hold (Inf where the scale overflowed fp16)."""
+        hi = self.t[:, :, 0]                                      # (B, G, Hp, Wp, 8)
+        if not self.tail:
+            return hi.abs().max().float(), None
+        c0 = self.C - self.tail
+        g0, k0 = c0 // 8, c0 % 8
+        tail = hi[:, g0:, :, :, :].abs()
+        tmax = tail[:, 0, :, :, k0:].max() if tail.shape[1] == 1 else torch.maximum(tail[:, 0, :, :, k0:].max(), tail[:, 1:].max())
+        body = torch.maximum(hi[:, :g0].abs().max(), tail[:, 0, :, :, :k0].max()) if k0 else hi[:, :g0].abs().max()
+        return body.float(), tmax.float()
 
     @property
     def B(self):
@@ -68,11 +92,23 @@ class _PackedC8:
     __slots__ = ("key", "img", "inv_scale", "bias")
 
 
-def packed_weights(layer, src_channels):
-    """Step images of `layer` for dkt_conv2d_c8, cached on the layer per device and operand split."""
+def _in_scale_vector(seg_lists, device):
+    """1 / scale per input channel for operands whose channel_scales() are `seg_lists` (None when every scale is 1)."""
+    segs = [sg for lst in seg_lists for sg in lst]
+    if all(sc == 1.0 for _, sc in segs):
+        return None
+    return torch.cat([torch.full((n,), 1.0 / sc, device=device, dtype=torch.float32) for n, sc in segs])
+
+
+def packed_weights(layer, src_channels, src_scales=None):
+    """Step images of `layer` for dkt_conv2d_c8, cached on the layer per device and operand split.  `src_scales`: the
+    operands' channel_scales(); their inverses are folded into the weights (powers of two: exact)."""
     with _CACHE_LOCK:
         w, b = layer.weight, layer.bias
-        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(src_channels))
+        scales = tuple(tuple(x) for x in src_scales) if src_scales is not None else None
+        if scales is not None and all(sc == 1.0 for lst in scales for _, sc in lst):
+            scales = None
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(src_channels), scales)
         cache = layer.__dict__.setdefault("_dkt_packed_c8", {})
         slot = (str(w.device), tuple(src_channels))
         hit = cache.get(slot)
@@ -87,11 +123,14 @@ def packed_weights(layer, src_channels):
         nbytes = L.dkt_conv_c8_packed_bytes(ch, n, cout)
         if nbytes <= 0:
             raise _ffi.DktError("dkt_conv_c8_packed_bytes rejected the layer shape")
-        wmax = float(w.detach().abs().max())
+        wc = w.detach().float()
+        if scales is not None:
+            wc = wc * _in_scale_vector(scales, w.device).view(1, -1, 1, 1)
+        wc = wc.contiguous()
+        wmax = float(wc.abs().max())
         e = 12 - math.floor(math.log2(wmax)) if wmax > 0 else 0       # max|w| in [2^12, 2^13): w_lo stays normal
         p = _PackedC8()
         p.img = torch.zeros(nbytes // 2, device=w.device, dtype=torch.float16)
-        wc = w.detach().float().contiguous()
         rc = L.dkt_conv_c8_pack_weights(wc.data_ptr(), ch, n, cout, 2.0 ** e, p.img.data_ptr(), _ffi.device_of(w), _ffi.stream_of(w))
         _ffi.check(rc, "dkt_conv_c8_pack_weights")
         p.inv_scale = 2.0 ** -e
@@ -125,13 +164,16 @@ class _PackedGru:
     __slots__ = ("key", "wzr", "wq", "inv_zr", "inv_q", "bz", "br", "bq")
 
 
-def gru_packed(gru, x_channels):
+def gru_packed(gru, x_channels, h_scales=None, x_scales=None):
     """Weights of one ConvGRU (core/update.py:16-21) for dkt_gru_c8: the z|r image with its output channels interleaved in
     blocks of 32 (a wave holds z and r of the same hidden channels), the q image with its input channels reordered to
-    [x... | r*h] (the x chunks are consumed before the neighbours' r*h is needed).  Cached on the module per device."""
+    [x... | r*h] (the x chunks are consumed before the neighbours' r*h is needed).  `h_scales` / `x_scales`: channel_scales()
+    of the state (= of r*h) and of the x operands, folded into the weights.  Cached on the module per device."""
     with _CACHE_LOCK:
         ps = [gru.convz.weight, gru.convr.weight, gru.convq.weight, gru.convz.bias, gru.convr.bias, gru.convq.bias]
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (tuple(x_channels),)
+        hs = tuple(h_scales) if h_scales is not None else ((128, 1.0),)
+        xs = tuple(tuple(x) for x in x_scales) if x_scales is not None else tuple(((c, 1.0),) for c in x_channels)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (tuple(x_channels), hs, xs)
         cache = gru.__dict__.setdefault("_dkt_gru_c8", {})
         slot = (str(ps[0].device), tuple(x_channels))
         hit = cache.get(slot)
@@ -141,6 +183,9 @@ def gru_packed(gru, x_channels):
         ch, cin = int(wz.shape[0]), int(wz.shape[1])
         if ch != 128 or cin != ch + sum(x_channels):
             raise ValueError("gru_c8: hidden size 128, operands of %d channels expected" % (cin - ch))
+        inv = _in_scale_vector([hs] + list(xs), wz.device)            # the reference's input order [h | x...] (= [r*h | x...])
+        if inv is not None:
+            wz, wr, wq = (w * inv.view(1, -1, 1, 1) for w in (wz, wr, wq))
         wzr = torch.stack([wz.view(ch // 32, 32, cin, 3, 3), wr.view(ch // 32, 32, cin, 3, 3)], dim=1).reshape(2 * ch, cin, 3, 3)
         wq2 = torch.cat([wq[:, ch:], wq[:, :ch]], dim=1)
         p = _PackedGru()
@@ -161,13 +206,15 @@ def gru_desc(gru, h_c8, xs, rh_c8, cz, cr, cq, h, flags):
     """dkt_gru_c8_desc of one ConvGRU step: h (fp32 NCHW) and its C8S twin h_c8 are updated in place."""
     xs = list(xs)
     for s in xs + [rh_c8]:
-        if (s.H, s.W, s.B) != (h_c8.H, h_c8.W, h_c8.B) or s.scale != h_c8.scale:
-            raise ValueError("gru_c8: operands must share batch, size and activation scale")
+        if (s.H, s.W, s.B) != (h_c8.H, h_c8.W, h_c8.B):
+            raise ValueError("gru_c8: operands must share batch and size")
+    if rh_c8.scale != h_c8.scale or h_c8.tail or rh_c8.tail:
+        raise ValueError("gru_c8: the state and the r*h scratch carry one common scale")
     HW = h_c8.H * h_c8.W
     for t in (cz, cr, cq, h):
         if t.shape[1:] != (128, h_c8.H, h_c8.W) or t.stride(3) != 1 or t.stride(2) != h_c8.W or t.stride(1) != HW:
             raise ValueError("gru_c8: context terms and state are fp32 (B, 128, H, W), dense per batch item")
-    pk = gru_packed(gru, [s.C for s in xs])
+    pk = gru_packed(gru, [s.C for s in xs], h_c8.channel_scales(), [s.channel_scales() for s in xs])
     d = _ffi.GruC8Desc()
     d.h_c8, d.h_c8_bstride = h_c8.data_ptr(), h_c8.bstride_bytes
     for i, s in enumerate(xs):
@@ -179,7 +226,7 @@ def gru_desc(gru, h_c8, xs, rh_c8, cz, cr, cq, h, flags):
     d.cz, d.cr, d.cq = cz.data_ptr(), cr.data_ptr(), cq.data_ptr()
     d.cz_bstride, d.cr_bstride, d.cq_bstride = cz.stride(0), cr.stride(0), cq.stride(0)
     d.h, d.h_bstride = h.data_ptr(), h.stride(0)
-    d.scale_zr, d.scale_q, d.act_scale = pk.inv_zr / h_c8.scale, pk.inv_q / h_c8.scale, h_c8.scale
+    d.scale_zr, d.scale_q, d.act_scale = pk.inv_zr, pk.inv_q, h_c8.scale      # (operand scales live in the packed weights)
     d.B, d.H, d.W, d.hidden = h_c8.B, h_c8.H, h_c8.W, 128
     d.flags = flags.data_ptr()
     d._keep = (h_c8, xs, rh_c8, pk, cz, cr, cq, h, flags)
@@ -222,9 +269,9 @@ def desc(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, epilogue=
     srcs = list(srcs)
     s0 = srcs[0]
     for s in srcs:
-        if (s.H, s.W, s.B) != (s0.H, s0.W, s0.B) or s.scale != s0.scale:
-            raise ValueError("conv2d_c8: operands must share batch, size and activation scale")
-    pk = packed_weights(layer, [s.C for s in srcs])
+        if (s.H, s.W, s.B) != (s0.H, s0.W, s0.B):
+            raise ValueError("conv2d_c8: operands must share batch and size")
+    pk = packed_weights(layer, [s.C for s in srcs], [s.channel_scales() for s in srcs])
     d = _ffi.ConvC8Desc()
     for i, s in enumerate(srcs):
         d.src[i] = s.data_ptr()
@@ -233,7 +280,7 @@ def desc(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, epilogue=
     d.nsrc = len(srcs)
     d.w = pk.img.data_ptr()
     d.bias = None if pk.bias is None else pk.bias.data_ptr()
-    d.out_scale = pk.inv_scale / s0.scale
+    d.out_scale = pk.inv_scale               # (the operands' scales are folded into the packed weights)
     d.act_scale = 1.0
     d.B, d.H, d.W, d.Cout, d.relu = s0.B, s0.H, s0.W, int(layer.weight.shape[0]), int(bool(relu))
     d.epilogue = epilogue
@@ -247,6 +294,10 @@ def desc(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, epilogue=
             setattr(d, name + "_bstride", a.bstride_bytes)
             setattr(d, name + "_ch0", c0)
             d.act_scale = a.scale
+            if name == "out_c8" and tail is not None and a.tail:
+                if a.tail != int(tail.shape[1]) or c0 + int(layer.weight.shape[0]) + a.tail != a.C:
+                    raise ValueError("conv2d_c8: the destination's tail channels are not where this layer appends them")
+                d.tail_scale = a.tail_scale
     for name, t in (("e0", e0), ("e1", e1), ("h", h), ("out2", out2), ("tail", tail)):
         if t is not None:
             setattr(d, name, t.data_ptr())

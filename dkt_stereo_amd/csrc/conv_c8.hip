@@ -62,6 +62,7 @@ struct C8Args {
     float *head_out; long head_out_bs; int head_nout;
     int f32_c4;                        // the fp32 tensors above (out, out2, e_c0, e_c1, e_h) are [B][C/4][H][W][4] instead of NCHW
     const float *tail; long tail_bs; int tail_ch;   // epi 0: channels Cout .. Cout+tail_ch-1 of the C8S output are copied from here
+    float tail_ratio;                  // ... times tail_scale / act_scale (the tail channels may carry their own power-of-two scale)
 };
 
 struct C8ArgsPair {
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
                                 if (cl + i >= a.Cout) {
                                     y = 0.0f;
                                     if (a.tail && cl + i < a.Cout + a.tail_ch && inside)
-                                        y = a.tail[(long)b * a.tail_bs + (long)(cl + i - a.Cout) * iHW + px];
+                                        y = a.tail[(long)b * a.tail_bs + (long)(cl + i - a.Cout) * iHW + px] * a.tail_ratio;
                                 }
                                 v[jj][i] = y;
                             }
@@ -851,6 +852,7 @@ static int c8_fill(C8Args &a, const dkt_conv_c8_desc *d) {
     if (a.epi == 3 && (!a.head_w || !a.head_out || !a.bias)) return DKT_E_NULL;
     if (a.epi == 3 && (a.head_nout != 1 || a.Cout % 64 != 0)) return DKT_E_UNSUPPORTED;       // one output (stereo heads); the 2-output flow head keeps the hidden tensor
     a.tail = d->tail; a.tail_bs = d->tail_bstride; a.tail_ch = d->tail ? d->tail_channels : 0;
+    a.tail_ratio = d->tail_scale > 0.0f ? d->tail_scale / d->act_scale : 1.0f;
     if ((a.out_c8_ch0 & 7) || (a.out2_c8_ch0 & 7)) return DKT_E_SHAPE;
     if (a.epi == 1) {
         if (!d->e0 || !d->e1 || !d->h || (!d->out2 && !d->out2_c8) || !d->out) return DKT_E_NULL;

@@ -62,6 +62,8 @@ def _iterate_c8(ub, st, iters):
     if lp is None:
         lp = st.c8 = loop_c8.C8LoopIGEV(ub, d)
     with harness(inplace_state=True, side_stream=False):
+        if not lp.calibrated:
+            lp.calibrate(d, iters)               # activation scales from a trial run on this pair (state restored)
         lp.prologue(d)
         keep = None
         for k in range(iters):

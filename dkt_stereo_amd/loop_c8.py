@@ -8,6 +8,7 @@ overlap usefully on this part, tools/concurrency_probe.py):
     prologue: gru32(0)
     unit(i) : gru16(i) ; lookup + motion encoder(i) ; gru08(i) paired with gru32(i+1) ; flow head(i)
 Every GRU sees exactly the operands of the reference's sequential order."""
+import math
 import os
 
 import torch
@@ -28,6 +29,14 @@ if os.environ.get("DKT_C8_CFG"):
 #: round 4: the finest GRU (with the coarsest one of the next iteration riding along) as ONE launch per step (csrc/gru_c8.hip:
 #: z|r -> gates -> q -> h' per tile, neighbour flags instead of a kernel boundary); DKT_C8_FUSE_GRU=0: two launches per step
 FUSE_GRU = os.environ.get("DKT_C8_FUSE_GRU", "1") != "0"
+
+#: round 4: every C8S tensor of the loop carries a power-of-two scale picked from the magnitudes one trial unit produces
+#: (C8Loop.calibrate): max |x * scale| lands in [2^SCALE_EXP, 2^(SCALE_EXP + 1)), i.e. 5 bits below fp16's overflow and with
+#: hi AND lo halves in fp16's normal range down to 2^-13 of the tensor's maximum.  DKT_C8_AUTOSCALE=0: scale 1 everywhere
+AUTOSCALE = os.environ.get("DKT_C8_AUTOSCALE", "1") != "0"
+SCALE_EXP = 10
+#: a later forward whose maxima leave [2^RANGE_LO, 2^RANGE_HI) after scaling recalibrates (checked where finiteness is)
+RANGE_LO, RANGE_HI = 6, 14
 
 #: quarter-resolution pixels (per pair) from which the loop takes this path: the C8S kernel's tiles are 8 rows x 32 columns
 #: x 64-256 channels, smaller images leave most CUs without one (256 x 512: 7.4 ms against 5.4 on the round-2 kernels)
@@ -70,7 +79,8 @@ class C8Loop:
         A = lambda t, C=128: c8.ActC8(B, C, t.shape[2], t.shape[3], dev)
         self.hc8 = [A(n0), A(n1), A(n2)]
         self.rh = [A(n0), A(n1), A(n2)]
-        self.up1, self.mf = A(n0), A(n0)                  # gru08 operands: interp(net[1]), motion features
+        self.up1 = A(n0)                                  # gru08 operands: interp(net[1]), motion features (+ flow / disparity tail)
+        self.mf = c8.ActC8(B, 128, n0.shape[2], n0.shape[3], dev, tail=self._tail_channels)
         self.pool0, self.up2 = A(n1), A(n1)               # gru16 operands: pool2x(net[0]), interp(net[2])
         self.pool1 = A(n2)                                # gru32 operand: pool2x(net[1])
         self.cor, self.flo = A(n0, 64), A(n0, 64)
@@ -81,6 +91,81 @@ class C8Loop:
         self.err = torch.zeros(1, device=dev, dtype=torch.int32)
         self.fuse_gru = FUSE_GRU
         self.graph = None
+        self.calibrated = not AUTOSCALE
+
+    _tail_channels = 2                   # flow (x, y) behind the 126 motion features (core/update.py:85)
+
+    # ---- activation scales ----------------------------------------------------------------------------------------
+    def _scaled(self):
+        """C8S tensors with a scale of their own (the r*h scratch shares its level's state scale)."""
+        return [*self.hc8, self.up1, self.mf, self.pool0, self.up2, self.pool1, self.cor, self.flo, self.cf]
+
+    def _state(self, st):
+        """Tensors a unit changes (restored after the trial unit)."""
+        return [*st["net"], st["coords1"], st["flow"]]
+
+    def _maxima_dev(self, acts=None):
+        vals = []
+        for a in (self._scaled() if acts is None else acts):
+            body, tail = a.absmax()
+            vals += [body, tail if tail is not None else body.new_zeros(())]
+        return torch.stack(vals)
+
+    def _maxima(self, acts=None):
+        return self._maxima_dev(acts).cpu().tolist()
+
+    def _rescale(self, m):
+        """New scales from the maxima `m` (scaled units, _maxima order).  Returns True when a value overflowed fp16 (scale far
+        too large: the caller runs another trial with the reduced scales)."""
+        overflow = False
+
+        def pick(scale, v):
+            nonlocal overflow
+            if not math.isfinite(v):
+                overflow = True
+                return scale * 2.0 ** -12
+            if v <= 0.0:
+                return scale
+            return scale * 2.0 ** (SCALE_EXP - math.floor(math.log2(v)))
+
+        for i, a in enumerate(self._scaled()):
+            a.scale = pick(a.scale, m[2 * i])
+            a.tail_scale = pick(a.tail_scale, m[2 * i + 1]) if a.tail else a.scale
+        for lvl in range(3):
+            self.rh[lvl].scale = self.rh[lvl].tail_scale = self.hc8[lvl].scale
+        return overflow
+
+    def calibrate(self, st, iters):
+        """Picks every C8S tensor's scale from a trial run of the loop on the pair at hand -- all `iters` units: the flow
+        features grow with the disparity the iterations find -- and restores the state afterwards, so that no caller has to
+        run conv.calibrate() and no layer silently computes from operands below fp16's normal range.  Once per (shape,
+        weights) state; weights are re-packed with the new scales on their next use."""
+        keep = [t.clone() for t in self._state(st)]
+        for _ in range(4):
+            self.prologue(st)
+            m = None
+            for _ in range(max(1, iters)):
+                self.unit(st)
+                cur = self._maxima_dev()
+                m = cur if m is None else torch.maximum(m, cur)        # (NaN / Inf propagate: an overflow is not missed)
+            overflow = self._rescale(m.cpu().tolist())
+            for t, k in zip(self._state(st), keep):
+                t.copy_(k)
+            if not overflow:
+                break
+        self.calibrated = True
+        self.graph = None                    # (a captured unit bakes the scales in)
+
+    def ranges_ok(self):
+        """False when a tensor's maximum has left [2^RANGE_LO, 2^RANGE_HI) under its scale (another kind of input than the one
+        calibrated on): the caller recalibrates and repeats the forward."""
+        if not AUTOSCALE:
+            return True
+        # (the state-like tensors are bounded by 1: only the motion encoder's tensors follow the input's magnitudes)
+        for v in self._maxima([self.cor, self.flo, self.cf, self.mf]):
+            if v != 0.0 and not (2.0 ** RANGE_LO <= v < 2.0 ** RANGE_HI):
+                return False
+        return True
 
     @staticmethod
     def _gru_modules(ub):
@@ -174,9 +259,14 @@ class C8LoopIGEV(C8Loop):
     features and the one-output disparity head whose result is added to the running disparity in dkt_head_finish.
     ``st``: dict(net, inp, disp, coords, geo_fn)."""
 
+    _tail_channels = 1                   # the running disparity behind the 127 motion features (igev_stereo/update.py:92)
+
     @staticmethod
     def _gru_modules(ub):
         return ub.gru04, ub.gru08, ub.gru16
+
+    def _state(self, st):
+        return [*st["net"], st["disp"]]
 
     def _motion(self, st):
         enc = self.ub.encoder

@@ -457,6 +457,8 @@ class RAFTStereo(nn.Module):
         torch.sub(st["coords1"], st["coords0"], out=st["flow"])
         ub = self.update_block
         with harness(inplace_state=True, side_stream=False):
+            if not lp.calibrated:
+                lp.calibrate(st, iters)      # activation scales from a trial run on this pair (state restored)
             lp.prologue(st)
             done = 0
             if self.c8_eager:                # (bench.py's instrumented pass: every unit as plain launches)
@@ -643,6 +645,11 @@ class RAFTStereo(nn.Module):
             if lp is not None and int(lp.err.item()):
                 raise _ffi.DktError("the fused ConvGRU launch timed out waiting for a neighbour tile (csrc/gru_c8.hip): "
                                     "the device did not keep the launch's blocks resident; set DKT_C8_FUSE_GRU=0")
+            if lp is not None and lp.calibrated and (not finite or not lp.ranges_ok()):
+                # this pair's activations left the window the C8S scales were picked for: pick again, repeat the forward
+                lp.calibrated = False
+                flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+                finite = bool(torch.isfinite(flow_up).all())
         if not finite:
             raise _ffi.DktError(
                 "RAFTStereo.forward produced non-finite disparities: an activation left the range of the "

@@ -460,6 +460,8 @@ typedef struct dkt_conv_c8_desc {
     int head_outputs;                       /*   1 (stereo: x only / disparity) or 2 */
     int f32_c4;                             /* 1: out, out2, e0, e1, h are "C4" tensors [B][ceil(C/4)][H][W][4] (one 16-byte access per
                                              * lane and channel quad in the epilogue) instead of NCHW; bstrides stay in floats */
+    float tail_scale;                       /* power of two applied to the `tail` channels of the C8S output instead of act_scale
+                                             * (0 = act_scale): flow / disparity values next to features of another magnitude */
 } dkt_conv_c8_desc;
 /* cfg: 0 = tile shape by layer / image size, 1..5 force one (conv_c8.hip c8_dispatch). */
 int dkt_conv2d_c8(const dkt_conv_c8_desc *d, int cfg, int device, void *stream);

@@ -171,3 +171,57 @@ def test_fused_gru_argument_errors():
     assert _ffi.lib().dkt_gru_c8(ctypes.byref(d), None, 0, None) < 0
     with pytest.raises(ValueError):
         c8.gru_desc(s.gru, s.hc8, s.xs, c8.ActC8(1, 128, 16, 64, DEV), s.cz, s.cr, s.cq, s.h, s.flags)
+
+
+def _rescaled_state_dict(sd, k):
+    """The same function with the update block's unbounded activations (correlation / flow features, their 64-channel
+    successors, the motion features, the flow head's hidden tensor) multiplied by 2^k: every layer between two of them is
+    positively homogeneous (conv + ReLU), so scaling a layer's weights and bias by 2^k and dividing its consumers' weights
+    for those channels by 2^k changes nothing -- exactly nothing in fp32, powers of two commute with rounding."""
+    s = 2.0 ** k
+    sd = {n: v.clone() for n, v in sd.items()}
+    enc = "update_block.encoder."
+    for name in ("convc1", "convf1"):
+        sd[enc + name + ".weight"] *= s
+        sd[enc + name + ".bias"] *= s
+    for name in ("convc2", "convf2", "conv"):          # input and output both scaled: weights unchanged, bias scaled
+        sd[enc + name + ".bias"] *= s
+    for g in ("convz", "convr", "convq"):              # gru08 reads [h (128) | motion features (126) + flow (2) | interp (128)]
+        sd["update_block.gru08.%s.weight" % g][:, 128:254] /= s
+    sd["update_block.flow_head.conv1.weight"] *= s
+    sd["update_block.flow_head.conv1.bias"] *= s
+    sd["update_block.flow_head.conv2.weight"] /= s
+    return sd
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("k", [-10, 10])
+def test_default_path_holds_the_bound_when_activations_sit_at_1e_3_or_1e3(k, golden):
+    """the C8S format has 22 significant bits only inside fp16's normal range.  With the update block's
+    activations at 2^-10 (~1e-3) or 2^10 (~1e3) of their usual size the DEFAULT path (no conv.calibrate()) must still be within
+    1e-3 of the reference's output on the benchmark workload -- the reference's own fixture applies unchanged, the rescaling is
+    exact in its fp32 arithmetic."""
+    import math
+    import _cases
+    import _synth
+    from test_gpu_parity import G, _raft, maxabs
+    c = _cases.E2E_CASES["736x1248_it32"]
+    g = golden("raft_e2e")
+    st = int(g["736x1248_it32/stride"])
+    model, sd = _raft()
+    i1, i2 = (G(t) for t in _synth.image_pair(c["seed"], 1, c["H"], c["W"], c["shift"]))
+    _, up = model(i1, i2, iters=32, test_mode=True)
+    base = maxabs(up[:, :, ::st, ::st], g["736x1248_it32/flow_up"])
+    lp = model._graph_state["c8"]
+    assert lp.calibrated
+    e0 = {n: math.log2(getattr(lp, n).scale) for n in ("cor", "flo", "cf", "mf")}
+    t0 = lp.mf.tail_scale
+    model.load_state_dict(_rescaled_state_dict(sd, k), strict=True)
+    _, up = model(i1, i2, iters=32, test_mode=True)
+    d = maxabs(up[:, :, ::st, ::st], g["736x1248_it32/flow_up"])
+    print("activations x 2^%d: %.3e from the reference fixture (unscaled weights: %.3e)" % (k, d, base))
+    assert d <= 1e-3
+    lp = model._graph_state["c8"]
+    e1 = {n: math.log2(getattr(lp, n).scale) for n in e0}
+    assert all(e1[n] == e0[n] - k for n in e0), (e0, e1)          # the scales followed the activations
+    assert lp.mf.tail_scale == t0 and lp.mf.tail_scale != lp.mf.scale          # the flow channels kept theirs
