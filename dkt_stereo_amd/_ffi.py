@@ -29,7 +29,8 @@ class ConvDesc(ctypes.Structure):
                 ("epilogue", ctypes.c_int), ("e0", ctypes.c_void_p), ("e0_bstride", ctypes.c_long),
                 ("e1", ctypes.c_void_p), ("e1_bstride", ctypes.c_long), ("h", ctypes.c_void_p),
                 ("h_bstride", ctypes.c_long), ("out2", ctypes.c_void_p), ("out2_bstride", ctypes.c_long),
-                ("in_norm", ctypes.c_void_p)]
+                ("in_norm", ctypes.c_void_p), ("stride", ctypes.c_int), ("stats_ws", ctypes.c_void_p),
+                ("stats_part", ctypes.c_void_p)]
 
 
 class ConvC8Desc(ctypes.Structure):
@@ -66,6 +67,7 @@ class GruC8Desc(ctypes.Structure):
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
     "dkt_gru_c8_flag_words": [_i, _i, _i],
+    "dkt_conv2d_stats_ws_floats": [_i, _i, _i, _i],
     "dkt_gru_c8": [ctypes.POINTER(GruC8Desc), _vp, _i, _vp],
     "dkt_gru_c8_pair": [ctypes.POINTER(GruC8Desc), ctypes.POINTER(GruC8Desc), _vp, _i, _vp],
     "dkt_build_ablation": [],
@@ -141,7 +143,7 @@ SIGNATURES = {
     "dkt_interp_bilinear": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
 }
 #: entry points that do not return an int status
-RESTYPES = {"dkt_gru_c8_flag_words": ctypes.c_long, "dkt_conv_c8_packed_bytes": ctypes.c_long, "dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
+RESTYPES = {"dkt_gru_c8_flag_words": ctypes.c_long, "dkt_conv2d_stats_ws_floats": ctypes.c_long, "dkt_conv_c8_packed_bytes": ctypes.c_long, "dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
 
 #: DKT_E_UNSUPPORTED of include/dktstereo.h
 E_UNSUPPORTED = -7

@@ -430,6 +430,48 @@ def conv2d_fused(x, layer, relu=False, residual=None, in_norm=None):
     return out
 
 
+class OutStats:
+    """Instance-norm statistics of a convolution's output, accumulated in its epilogue: `part` is the partial-sum workspace
+    the dkt_instance_norm_* kernels read (what dkt_instance_norm_stats would have written in a pass of its own)."""
+    __slots__ = ("part", "planes", "hw")
+
+    def __init__(self, part, planes, hw):
+        self.part, self.planes, self.hw = part, planes, hw
+
+
+def stats_eligible(layer):
+    """`layer` can accumulate its output's instance-norm statistics in the epilogue (dkt_conv_desc.stats_ws): the split-fp16
+    kernel's plain epilogue, stride 1 or 2."""
+    return hip_eligible(layer) and _stride_of(layer) in ((1, 1), (2, 2)) and not direct_eligible(layer) and not few_eligible(layer)
+
+
+def conv2d_stats(x, layer, in_norm=None):
+    """conv(x) + bias with the statistics of its OWN output for the InstanceNorm2d that follows it
+    (core/extractor.py:46-50): returns (out, OutStats).  `in_norm` as in conv2d_fused (stride 1 only)."""
+    op = _Operands(x, layer)
+    stride = _stride_of(layer)[0]
+    Ho, Wo = (op.H - 1) // stride + 1, (op.W - 1) // stride + 1
+    out = torch.empty((op.B, op.cout, Ho, Wo), device=op.device, dtype=torch.float32)
+    L = _ffi.lib()
+    d = _desc(op, out)
+    d.stride = stride
+    planes = op.B * op.cout
+    ws = torch.empty(int(L.dkt_conv2d_stats_ws_floats(op.B, op.cout, Ho, Wo)), device=op.device, dtype=torch.float32)
+    part = torch.empty(int(L.dkt_instance_norm_workspace(planes, Ho * Wo)), device=op.device, dtype=torch.uint8)
+    d.stats_ws, d.stats_part = ws.data_ptr(), part.data_ptr()
+    keep = (ws, part)
+    if in_norm is not None:
+        if stride != 1 or op.n != 1 or in_norm.dtype != torch.float32 or in_norm.numel() != 2 * op.B * int(op.srcs[0].shape[1]):
+            raise ValueError("conv2d_stats: in_norm must hold (mean, 1/std) for every (batch, channel) plane of one operand")
+        in_norm = in_norm.contiguous()
+        d.in_norm = in_norm.data_ptr()
+        keep = keep + (in_norm,)
+    d._keep = d._keep + keep
+    rc = L.dkt_conv2d_f16s_desc(ctypes.byref(d), op.passes, _ffi.device_of(out), _ffi.stream_of(out))
+    _ffi.check(rc, "dkt_conv2d_f16s_desc")
+    return out, OutStats(part, planes, Ho * Wo)
+
+
 def pair_eligible(layer_a, layer_b):
     """Two stride-1 layers can share a launch (dkt_conv2d_f16s_pair): same filter size, same output-width class."""
     def cls(c):

@@ -97,7 +97,15 @@ struct ConvArgs {
     // Instance-norm of the INPUT folded into the staging (kernel instantiations with NRM = 1; one source):
     // (mean, 1/std) per (batch, channel) plane; the kernel convolves relu((x - mean) * invstd).
     const float *in_norm;
+    // Instance-norm statistics of the OUTPUT accumulated in the epilogue (epi 0): every wave writes the sums and sums of
+    // squares of its channels over its rows x 32 columns to stats_ws[((b * entries + e) * Cout + co) * 2 + {0, 1}], entry
+    // e = (tile index in the image) * WN + wave row; conv_stats_reduce (norm.hip) folds them into the fp64 partial-sum
+    // workspace the instance-norm kernels read (the statistics pass over the 235 MB activation disappears).
+    float *stats_ws;
+    double *stats_part;
+    long stats_hw;       // filled by launch_conv: plane size of the output
 };
+int conv_stats_reduce(const float *ws, double *part, int B, int C, long entries, long HW, hipStream_t st);      // norm.hip
 
 // Gate non-linearities for the fused epilogues.  The epilogue runs on the VALU after the
 // MFMA loop with nothing to overlap it, so it uses the hardware transcendentals
@@ -392,6 +400,56 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
                         if (all_co || co_lane + dco < a.Cout) op[dco * oHW] = v;
                     }
             }
+            if (a.stats_ws) {
+                // sums / sums of squares of the values just stored: per lane over its NF pixels, then a reduce-scatter over the
+                // 32 pixel lanes of the half-wave (31 exchanges per statistic instead of 160): lane li ends with value index li
+                constexpr int NV = MF * 16;
+                float s1[NV], s2[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) s1[i] = s2[i] = 0.0f;
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const int oh = h0 + wn * NF + n, ow = w0 + li;
+                    const bool ok = oh < a.Ho && ow < a.Wo;
+#pragma unroll
+                    for (int m = 0; m < MF; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[m][n][r] * a.out_scale + bv[m][r];
+                            if (a.relu) v = dkt_relu(v);
+                            v = ok ? v : 0.0f;
+                            s1[m * 16 + r] = __fadd_rn(s1[m * 16 + r], v);
+                            s2[m * 16 + r] = __fadd_rn(s2[m * 16 + r], __fmul_rn(v, v));
+                        }
+                }
+                if (NV == 16) {          // 16 values on 32 lanes: the first exchange only adds
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        s1[i] = __fadd_rn(s1[i], __shfl_xor(s1[i], 16, 32));
+                        s2[i] = __fadd_rn(s2[i], __shfl_xor(s2[i], 16, 32));
+                    }
+                }
+#pragma unroll
+                for (int d = (NV == 16 ? 8 : 16); d >= 1; d >>= 1) {
+                    const bool up = (li & d) != 0;
+#pragma unroll
+                    for (int j = 0; j < d; ++j) {
+                        const float k1 = up ? s1[j + d] : s1[j], g1 = up ? s1[j] : s1[j + d];
+                        const float k2 = up ? s2[j + d] : s2[j], g2 = up ? s2[j] : s2[j + d];
+                        s1[j] = __fadd_rn(k1, __shfl_xor(g1, d, 32));
+                        s2[j] = __fadd_rn(k2, __shfl_xor(g2, d, 32));
+                    }
+                }
+                const int vi = NV == 16 ? (li & 15) : li;                 // value index this lane holds
+                const int dco = (vi >> 4) * 32 + (vi & 3) + 8 * ((vi & 15) >> 2);
+                const int co = co_lane + dco;
+                const long e = (long)((h0 / (NF * WN)) * a.tiles_w + w0 / 32) * WN + wn;
+                if (co < a.Cout && (NV == 32 || li < 16)) {
+                    float *p = a.stats_ws + (((long)b * a.tiles_xy * WN + e) * a.Cout + co) * 2;
+                    p[0] = s1[0];
+                    p[1] = s2[0];
+                }
+            }
             return;
         }
         // ---- fused GRU gates (gru_gates.hip arithmetic with hardware exp/rcp) ----
@@ -649,8 +707,12 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec 
         ap.p[0] = a;
         ap.p[1] = a;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, ap, (int)nblk);
-        return dkt_launch_status();
+        int rc = dkt_launch_status();
+        if (rc == DKT_OK && a.stats_ws)
+            rc = conv_stats_reduce(a.stats_ws, a.stats_part, B, a.Cout, (long)a.tiles_xy * WN, (long)a.Ho * a.Wo, st);
+        return rc;
     }
+    if (a.stats_ws || sec->a.stats_ws) return DKT_E_UNSUPPORTED;
     // ---- two problems: resident blocks are split in proportion to the work (tiles x chunks)
     ConvArgs b = sec->a;
     b.tiles_xy = b.tiles_w * ((b.Ho + NF * WN - 1) / (NF * WN));
@@ -842,6 +904,9 @@ static int conv_fill(ConvArgs &a, const float *const *src, const int *src_channe
     a.out2 = nullptr;
     a.out2_bs = 0;
     a.in_norm = nullptr;
+    a.stats_ws = nullptr;
+    a.stats_part = nullptr;
+    a.stats_hw = 0;
     if (epi) {
         a.epi = epi->kind;
         a.e_c0 = epi->c0; a.e_c1 = epi->c1; a.e_h = epi->h;
@@ -883,11 +948,19 @@ static int conv_fill_desc(ConvArgs &a, const dkt_conv_desc *d, int passes) {
     } else if (d->epilogue == 3) {
         if (!d->e0) return DKT_E_NULL;
     }
+    const int stride = d->stride == 2 ? 2 : 1;
+    if (d->stride != 0 && d->stride != 1 && d->stride != 2) return DKT_E_UNSUPPORTED;
     const int rc = conv_fill(a, d->src, d->src_channels, d->src_bstride, d->nsrc, d->w_hi, d->w_lo, d->bias, d->out_scale,
                              d->in_scale, d->out, d->out_bstride, d->B, d->H, d->W, d->Cout, d->KH, d->KW,
                              d->relu, passes,
-                             d->epilogue ? &e : nullptr, 1);
+                             d->epilogue ? &e : nullptr, stride);
     if (rc != DKT_OK) return rc;
+    if (d->stats_ws || d->stats_part) {
+        if (!d->stats_ws || !d->stats_part) return DKT_E_NULL;
+        if (d->epilogue != 0) return DKT_E_UNSUPPORTED;
+        a.stats_ws = d->stats_ws;
+        a.stats_part = (double *)d->stats_part;
+    }
     if (d->in_norm) {
         if (d->nsrc != 1 || d->KH != 3 || d->Cout <= 32 || d->Cout > 128 || d->epilogue == 1 || d->epilogue == 2)
             return DKT_E_UNSUPPORTED;
@@ -898,12 +971,17 @@ static int conv_fill_desc(ConvArgs &a, const dkt_conv_desc *d, int passes) {
 
 static int conv_width_class(int Cout) { return Cout <= 32 ? 0 : Cout <= 64 ? 1 : Cout <= 128 ? 2 : 3; }
 
+extern "C" long dkt_conv2d_stats_ws_floats(int B, int Cout, int Ho, int Wo) {
+    if (B <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0) return DKT_E_SHAPE;
+    return (long)B * ((Wo + 31) / 32) * Ho * Cout * 2;       // at most one entry per output row and 32-column strip
+}
+
 extern "C" int dkt_conv2d_f16s_desc(const dkt_conv_desc *p, int passes, int device, void *stream) {
     ConvArgs a;
     const int rc = conv_fill_desc(a, p, passes);
     if (rc != DKT_OK) return rc;
     DKT_ENTER(device);
-    return conv_dispatch(a, p->B, p->KH, 1, passes, (hipStream_t)stream, nullptr);
+    return conv_dispatch(a, p->B, p->KH, p->stride == 2 ? 2 : 1, passes, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc *p1, int passes, int device, void *stream) {
@@ -913,7 +991,7 @@ extern "C" int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc
     if (rc != DKT_OK) return rc;
     rc = conv_fill_desc(sec.a, p1, passes);
     if (rc != DKT_OK) return rc;
-    if (p0->in_norm || p1->in_norm) return DKT_E_UNSUPPORTED;
+    if (p0->in_norm || p1->in_norm || p0->stride == 2 || p1->stride == 2) return DKT_E_UNSUPPORTED;
     sec.B = p1->B;
     // both problems run one kernel instantiation: same filter size and the same output-width class
     if (p0->KH != p1->KH || conv_width_class(p0->Cout) != conv_width_class(p1->Cout)) return DKT_E_UNSUPPORTED;

@@ -100,6 +100,48 @@ static int instnorm_split(int planes, long HW) {
     return S;
 }
 
+// Statistics accumulated by a convolution's epilogue (conv2d.hip, ConvArgs.stats_ws: per (batch, entry, channel) fp32 sums
+// and sums of squares) folded into the partial-sum workspace the kernels above read: part[(plane * S + s) * 2 + {0, 1}].
+__global__ __launch_bounds__(256) void conv_stats_reduce_kernel(const float *__restrict__ ws, double *__restrict__ part,
+                                                                int C, long E, int S) {
+    const int plane = blockIdx.y, s = blockIdx.x;
+    const int b = plane / C, c = plane - b * C;
+    const long per = (E + S - 1) / S;
+    const long lo = (long)s * per;
+    long hi = lo + per;
+    if (hi > E) hi = E;
+    double sum = 0.0, sq = 0.0;
+    for (long e = lo + threadIdx.x; e < hi; e += 256) {
+        const float2 v = *(const float2 *)(ws + (((long)b * E + e) * C + c) * 2);
+        sum += (double)v.x;
+        sq += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_down(sum, o);
+        sq += __shfl_down(sq, o);
+    }
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][w] = sum;
+        red[1][w] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long)plane * S + s) * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((long)plane * S + s) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+int conv_stats_reduce(const float *ws, double *part, int B, int C, long entries, long HW, hipStream_t st) {
+    const long planes = (long)B * C;
+    if (planes <= 0 || planes > 65535 || entries <= 0) return DKT_E_SHAPE;
+    const int S = instnorm_split((int)planes, HW);
+    hipLaunchKernelGGL(conv_stats_reduce_kernel, dim3((unsigned)S, (unsigned)planes), dim3(256), 0, st, ws, part, C, entries, S);
+    return dkt_launch_status();
+}
+
 extern "C" int dkt_instance_norm_stats(const float *x, void *workspace, int planes, long HW, int device, void *stream) {
     if (!x || !workspace) return DKT_E_NULL;
     if (planes <= 0 || HW <= 0 || planes > 65535) return DKT_E_SHAPE;

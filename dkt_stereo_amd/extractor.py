@@ -15,10 +15,13 @@ import torch.nn.functional as F
 from . import _ffi
 import os
 
-from .conv import _CACHE_LOCK, conv2d, conv2d_fused, fused_eligible
+from .conv import _CACHE_LOCK, conv2d, conv2d_fused, conv2d_stats, fused_eligible, stats_eligible
 
 #: DKT_FUSE_ENCODER=0: separate normalise / residual-join passes around the encoders' convolutions (A/B switch)
 FUSE_ENCODER = os.environ.get("DKT_FUSE_ENCODER", "1") != "0"
+#: DKT_EPILOGUE_STATS=0: instance-norm statistics by a pass of their own (dkt_instance_norm_stats) instead of in the producing
+#: convolution's epilogue
+EPILOGUE_STATS = os.environ.get("DKT_EPILOGUE_STATS", "1") != "0"
 #: DKT_CNET_STREAMS=0: the context encoder's output heads one after the other on the trunk's stream
 CNET_STREAMS = os.environ.get("DKT_CNET_STREAMS", "1") != "0"
 
@@ -114,16 +117,20 @@ def conv_norm_act(conv, norm, x, relu):
     return norm_act(norm, conv(x), relu)
 
 
-def instance_norm_params(norm, x):
+def instance_norm_params(norm, x, stats=None):
     """(N*C, 2) float tensor of (mean, 1/sqrt(var + eps)) per plane of x (dkt_instance_norm_stats +
-    dkt_instance_norm_finalize): the `in_norm` operand of conv.conv2d_fused."""
+    dkt_instance_norm_finalize): the `in_norm` operand of conv.conv2d_fused.  `stats` (conv.OutStats): the partial sums the
+    convolution that produced x left behind -- the statistics pass is skipped."""
     x = x if x.is_contiguous() else x.contiguous()
     n, c, h, w = x.shape
     L = _ffi.lib()
-    ws = torch.empty(L.dkt_instance_norm_workspace(n * c, h * w), device=x.device, dtype=torch.uint8)
     out = torch.empty((n * c, 2), device=x.device, dtype=torch.float32)
-    rc = L.dkt_instance_norm_stats(x.data_ptr(), ws.data_ptr(), n * c, h * w, _ffi.device_of(x), _ffi.stream_of(x))
-    _ffi.check(rc, "dkt_instance_norm_stats")
+    if stats is not None:
+        ws = stats.part
+    else:
+        ws = torch.empty(L.dkt_instance_norm_workspace(n * c, h * w), device=x.device, dtype=torch.uint8)
+        rc = L.dkt_instance_norm_stats(x.data_ptr(), ws.data_ptr(), n * c, h * w, _ffi.device_of(x), _ffi.stream_of(x))
+        _ffi.check(rc, "dkt_instance_norm_stats")
     rc = L.dkt_instance_norm_finalize(ws.data_ptr(), n * c, h * w, float(norm.eps), out.data_ptr(),
                                       _ffi.device_of(x), _ffi.stream_of(x))
     _ffi.check(rc, "dkt_instance_norm_finalize")
@@ -134,11 +141,11 @@ def _plain_instance_norm(norm):
     return isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats
 
 
-def norm_add_relu(norm, x, c):
+def norm_add_relu(norm, x, c, c_stats=None):
     """relu(x + relu(norm(c))): the tail of a residual block.  With an affine-free instance norm
     (fnet) the normalisation of c is folded into the join (dkt_instance_norm_stats +
-    dkt_instance_norm_add_relu: one pass over c for the statistics, one fused pass), otherwise
-    norm_act + add_relu."""
+    dkt_instance_norm_add_relu: one pass over c for the statistics -- none when the producing convolution left them in
+    `c_stats` --, one fused pass), otherwise norm_act + add_relu."""
     lazy = x if isinstance(x, LazyNorm) else None
     if lazy is not None:
         x = lazy.raw
@@ -147,10 +154,13 @@ def norm_add_relu(norm, x, c):
         c = c.contiguous()
         n, ch, h, w = c.shape
         L = _ffi.lib()
-        ws = torch.empty(L.dkt_instance_norm_workspace(n * ch, h * w), device=c.device, dtype=torch.uint8)
         y = torch.empty_like(c)
-        rc = L.dkt_instance_norm_stats(c.data_ptr(), ws.data_ptr(), n * ch, h * w, _ffi.device_of(c), _ffi.stream_of(c))
-        _ffi.check(rc, "dkt_instance_norm_stats")
+        if c_stats is not None:
+            ws = c_stats.part
+        else:
+            ws = torch.empty(L.dkt_instance_norm_workspace(n * ch, h * w), device=c.device, dtype=torch.uint8)
+            rc = L.dkt_instance_norm_stats(c.data_ptr(), ws.data_ptr(), n * ch, h * w, _ffi.device_of(c), _ffi.stream_of(c))
+            _ffi.check(rc, "dkt_instance_norm_stats")
         if lazy is not None:
             rc = L.dkt_instance_norm_add_relu_lazy(x.data_ptr(), lazy.params.data_ptr(), int(lazy.relu), c.data_ptr(),
                                                    y.data_ptr(), ws.data_ptr(), n * ch, h * w, float(norm.eps),
@@ -170,15 +180,15 @@ class LazyNorm:
     (mean, 1/std).  Consumers fold the normalisation into their own pass (conv2d_fused(in_norm=...) reads it in its
     staging, dkt_instance_norm_add_relu_lazy applies it to the residual operand); ``materialize`` runs the plain pass."""
 
-    def __init__(self, norm, raw, relu):
-        self.norm, self.raw, self.relu = norm, raw, relu
+    def __init__(self, norm, raw, relu, stats=None):
+        self.norm, self.raw, self.relu, self.stats = norm, raw, relu, stats
         self._params = None
 
     @property
     def params(self):
         """(mean, 1/std) per plane, computed on first use (a consumer that materialises never needs them)."""
         if self._params is None:
-            self._params = instance_norm_params(self.norm, self.raw)
+            self._params = instance_norm_params(self.norm, self.raw, self.stats)
         return self._params
 
     def materialize(self):
@@ -241,18 +251,37 @@ class ResidualBlock(nn.Module):
         if fuse and _plain_instance_norm(self.norm1) and _plain_instance_norm(self.norm2) and fused_eligible(self.conv2, True):
             # fnet: relu(norm1(.)) between the two layers lives in conv2's staging (no normalise pass, the
             # intermediate is read once for its statistics and once by conv2)
+            # (round 4) the statistics each norm needs are accumulated by the convolution that produces its input
+            es = EPILOGUE_STATS
+            s1 = s2 = None
             if lazy is not None and lazy.relu and self.downsample is None and fused_eligible(self.conv1, True):
-                c1 = conv2d_fused(lazy.raw, self.conv1, in_norm=lazy.params)     # the block's input is normalised on the fly too
+                if es and stats_eligible(self.conv1):                            # the block's input is normalised on the fly too
+                    c1, s1 = conv2d_stats(lazy.raw, self.conv1, in_norm=lazy.params)
+                else:
+                    c1 = conv2d_fused(lazy.raw, self.conv1, in_norm=lazy.params)
             else:
                 if lazy is not None:
                     x, lazy = lazy.materialize(), None
-                c1 = self.conv1(x)
+                if es and stats_eligible(self.conv1):
+                    c1, s1 = conv2d_stats(x, self.conv1)
+                else:
+                    c1 = self.conv1(x)
             if self.downsample is not None:
                 # the projection's norm (no ReLU) is applied inside the join
-                x = LazyNorm(self.norm3, self.downsample[0](x), relu=False) if _plain_instance_norm(self.norm3) \
-                    else conv_norm_act(self.downsample[0], self.norm3, x, False)
-            c2 = conv2d_fused(c1, self.conv2, in_norm=instance_norm_params(self.norm1, c1))
-            return norm_add_relu(self.norm2, x, c2)
+                if _plain_instance_norm(self.norm3):
+                    if es and stats_eligible(self.downsample[0]):
+                        raw, s3 = conv2d_stats(x, self.downsample[0])
+                    else:
+                        raw, s3 = self.downsample[0](x), None
+                    x = LazyNorm(self.norm3, raw, relu=False, stats=s3)
+                else:
+                    x = conv_norm_act(self.downsample[0], self.norm3, x, False)
+            p1 = instance_norm_params(self.norm1, c1, s1)
+            if es and stats_eligible(self.conv2):
+                c2, s2 = conv2d_stats(c1, self.conv2, in_norm=p1)
+            else:
+                c2 = conv2d_fused(c1, self.conv2, in_norm=p1)
+            return norm_add_relu(self.norm2, x, c2, s2)
         if lazy is not None:
             x = lazy.materialize()
         y = conv_norm_act(self.conv1, self.norm1, x, True)

@@ -65,23 +65,20 @@ def _iterate_c8(ub, st, iters):
         if not lp.calibrated:
             lp.calibrate(d, iters)               # activation scales from a trial run on this pair (state restored)
         lp.prologue(d)
-        keep = None
-        for k in range(iters):
-            if k == iters - 1:
-                # every unit also advances the coarsest GRU for the NEXT iteration (it rides in the finest GRU's launches);
-                # the caller gets the state the reference's loop ends with
+        # every unit also advances the coarsest GRU for the NEXT iteration (it rides in the finest GRU's launches); the caller
+        # gets the state the reference's loop ends with: the coarsest state is saved in front of the last unit
+        done = 0
+        if lp.graph is None:
+            if iters == 1:
                 keep = st.net[2].clone()
-            if lp.graph is None:
-                lp.unit(d)                       # eager once: packs weights, sizes the allocator
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with capture_graph(g):
-                    lp.unit(d)
-                lp.graph = g                     # (capturing records, it does not execute)
-            else:
-                replay_graph(lp.graph)
-        if keep is not None:
-            st.net[2].copy_(keep)
+            lp.unit(d)                           # eager once: packs weights, sizes the allocator
+            lp.capture(d, capture_graph)         # (capturing records, it does not execute)
+            done = 1
+        if iters > done:
+            lp.replay(iters - 1 - done)
+            keep = st.net[2].clone()
+            lp.replay(1)
+        st.net[2].copy_(keep)
         mask = conv2d(st.net[0], ub.mask_feat_4[0], relu=True)
     return st.disp.clone(), mask, [t.clone() for t in st.net]
 

@@ -38,6 +38,10 @@ SCALE_EXP = 10
 #: a later forward whose maxima leave [2^RANGE_LO, 2^RANGE_HI) after scaling recalibrates (checked where finiteness is)
 RANGE_LO, RANGE_HI = 6, 14
 
+#: units per captured graph: a replay boundary costs ~8 us of idle device between two units (profiles/r04_pair_breakdown.txt), so
+#: the bulk of the iterations is replayed GRAPH_UNITS units at a time (a one-unit graph serves the remainder)
+GRAPH_UNITS = max(1, int(os.environ.get("DKT_C8_GRAPH_UNITS", "8")))
+
 #: quarter-resolution pixels (per pair) from which the loop takes this path: the C8S kernel's tiles are 8 rows x 32 columns
 #: x 64-256 channels, smaller images leave most CUs without one (256 x 512: 7.4 ms against 5.4 on the round-2 kernels)
 MIN_PIXELS = int(os.environ.get("DKT_C8_MIN_PIXELS", "24000"))
@@ -90,8 +94,33 @@ class C8Loop:
         self.gflags = [c8.gru_flags(B, n.shape[2], n.shape[3], dev) for n in (n0, n1, n2)]
         self.err = torch.zeros(1, device=dev, dtype=torch.int32)
         self.fuse_gru = FUSE_GRU
-        self.graph = None
+        self.graph = None                # one captured unit
+        self.graph_n = None              # GRAPH_UNITS captured units
         self.calibrated = not AUTOSCALE
+
+    # ---- captured units -------------------------------------------------------------------------------------------
+    def capture(self, st, capture_graph):
+        """Captures one unit, and GRAPH_UNITS units back to back (capturing records, it does not execute)."""
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with capture_graph(g):
+            self.unit(st)
+        self.graph = g
+        self.graph_n = None
+        if GRAPH_UNITS > 1:
+            gn = torch.cuda.CUDAGraph()
+            with capture_graph(gn):
+                for _ in range(GRAPH_UNITS):
+                    self.unit(st)
+            self.graph_n = gn
+
+    def replay(self, n):
+        """n units from the captured graphs."""
+        while self.graph_n is not None and n >= GRAPH_UNITS:
+            self.graph_n.replay()
+            n -= GRAPH_UNITS
+        for _ in range(n):
+            self.graph.replay()
 
     _tail_channels = 2                   # flow (x, y) behind the 126 motion features (core/update.py:85)
 
@@ -154,7 +183,7 @@ class C8Loop:
             if not overflow:
                 break
         self.calibrated = True
-        self.graph = None                    # (a captured unit bakes the scales in)
+        self.graph = self.graph_n = None     # (a captured unit bakes the scales in)
 
     def ranges_ok(self):
         """False when a tensor's maximum has left [2^RANGE_LO, 2^RANGE_HI) under its scale (another kind of input than the one

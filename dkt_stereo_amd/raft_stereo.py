@@ -468,13 +468,8 @@ class RAFTStereo(nn.Module):
             elif lp.graph is None:
                 lp.unit(st)                  # eager once: packs weights, sizes the allocator
                 done = 1
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with capture_graph(g):
-                    lp.unit(st)
-                lp.graph = g                 # (capturing does not execute: still one unit done)
-            for _ in range(iters - done):
-                replay_graph(lp.graph)
+                lp.capture(st, capture_graph)        # (capturing does not execute: still one unit done)
+            lp.replay(iters - done)
             # up-sampling mask head (core/update.py:107-110, :136) from the final hidden state: its 3x3 layer reads the C8S twin
             from . import conv_c8
             return .25 * conv2d(conv_c8.conv2d_c8([lp.hc8[0]], ub.mask[0], relu=True, cfg=1), ub.mask[2])

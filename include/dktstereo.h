@@ -334,7 +334,14 @@ typedef struct dkt_conv_desc {
     const float *in_norm;   /* optional, dkt_conv2d_f16s_desc only: (B*src_channels[0], 2) = (mean, 1/std) per input
                              * plane; the layer convolves relu((x - mean) * invstd) instead of x (nsrc = 1, 3x3,
                              * 32 < Cout <= 128).  NULL: plain input. */
+    int stride;             /* dkt_conv2d_f16s_desc only: 0 / 1 = stride 1, 2 = stride 2 (as dkt_conv2d_f16s_strided) */
+    float *stats_ws;        /* optional, dkt_conv2d_f16s_desc with epilogue 0: scratch of dkt_conv2d_stats_ws_floats floats; */
+    void *stats_part;       /* ... the instance-norm statistics of the OUTPUT (InstanceNorm2d of core/extractor.py:21-33 over
+                             * this layer's result) are accumulated in the epilogue and left in stats_part, a
+                             * dkt_instance_norm_workspace(B*Cout, Ho*Wo) buffer in the format dkt_instance_norm_stats writes
+                             * (dkt_instance_norm_finalize / _add_relu read it): the statistics pass disappears */
 } dkt_conv_desc;
+long dkt_conv2d_stats_ws_floats(int B, int Cout, int Ho, int Wo);
 int dkt_conv2d_f16s_pair(const dkt_conv_desc *p0, const dkt_conv_desc *p1, int passes, int device, void *stream);
 /* One stride-1 convolution given as a descriptor.  Besides the epilogues above:
  *   epilogue 3: residual join of a residual block whose norm is folded into the weights

@@ -225,3 +225,31 @@ def test_default_path_holds_the_bound_when_activations_sit_at_1e_3_or_1e3(k, gol
     e1 = {n: math.log2(getattr(lp, n).scale) for n in e0}
     assert all(e1[n] == e0[n] - k for n in e0), (e0, e1)          # the scales followed the activations
     assert lp.mf.tail_scale == t0 and lp.mf.tail_scale != lp.mf.scale          # the flow channels kept theirs
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [(2, 64, 64, 96, 160, 1, 3), (2, 64, 96, 96, 160, 2, 3), (1, 96, 128, 47, 81, 2, 3),
+                                   (2, 64, 96, 90, 130, 2, 1), (1, 128, 128, 40, 72, 1, 3), (3, 32, 40, 33, 70, 1, 3)])
+def test_conv_epilogue_statistics_match_the_statistics_pass(shape):
+    """dkt_conv_desc.stats_ws: the (mean, 1/std) an InstanceNorm2d needs of a convolution's output, accumulated in the
+    convolution's epilogue, against dkt_instance_norm_stats on the written output and against torch in fp64 -- every tile
+    shape the encoders use (stride 1 / 2, 1x1 / 3x3, ragged sizes, channel counts off the 32-channel grid)."""
+    from dkt_stereo_amd import conv, extractor
+    B, cin, cout, H, W, stride, k = shape
+    torch.manual_seed(cout + H)
+    layer = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2).to(DEV)
+    x = torch.randn(B, cin, H, W, device=DEV) * 2 + 0.5
+    norm = torch.nn.InstanceNorm2d(cout)
+    with conv.use_backend("f16x3"):
+        want_out = conv.conv2d(x, layer)
+        out, st = conv.conv2d_stats(x, layer)
+        assert torch.equal(out, want_out)
+        got = extractor.instance_norm_params(norm, out, st)
+        ref = extractor.instance_norm_params(norm, out)
+    o64 = out.double()
+    mean = o64.mean((2, 3)).reshape(-1)
+    invstd = 1.0 / torch.sqrt(o64.var((2, 3), unbiased=False).reshape(-1) + norm.eps)
+    scale = float(o64.abs().max())
+    assert float((got[:, 0].double() - mean).abs().max()) <= 2e-6 * scale
+    assert float((got[:, 1].double() / invstd - 1).abs().max()) <= 2e-6
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
