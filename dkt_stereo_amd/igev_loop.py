@@ -71,13 +71,13 @@ def _iterate_c8(ub, st, iters):
         if lp.graph is None:
             if iters == 1:
                 keep = st.net[2].clone()
-            lp.unit(d)                           # eager once: packs weights, sizes the allocator
+            lp.unit(d, last=(iters == 1))        # eager once: packs weights, sizes the allocator
             lp.capture(d, capture_graph)         # (capturing records, it does not execute)
             done = 1
         if iters > done:
             lp.replay(iters - 1 - done)
             keep = st.net[2].clone()
-            lp.replay(1)
+            lp.replay(1, last=True)
         st.net[2].copy_(keep)
         mask = conv2d(st.net[0], ub.mask_feat_4[0], relu=True)
     return st.disp.clone(), mask, [t.clone() for t in st.net]

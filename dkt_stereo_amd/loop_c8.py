@@ -38,6 +38,9 @@ SCALE_EXP = 10
 #: a later forward whose maxima leave [2^RANGE_LO, 2^RANGE_HI) after scaling recalibrates (checked where finiteness is)
 RANGE_LO, RANGE_HI = 6, 14
 
+#: the middle GRU's chain of the next iteration on a second stream beside the head and the motion encoder (DKT_C8_FORK=0: one stream)
+#: (=2: also the motion encoder's 7x7 stem beside the lookup on a third stream -- measured 0.25 ms per pair SLOWER, kept for A/B)
+FORK = int(os.environ.get("DKT_C8_FORK", "1"))
 #: units per captured graph: a replay boundary costs ~8 us of idle device between two units (profiles/r04_pair_breakdown.txt), so
 #: the bulk of the iterations is replayed GRAPH_UNITS units at a time (a one-unit graph serves the remainder)
 GRAPH_UNITS = max(1, int(os.environ.get("DKT_C8_GRAPH_UNITS", "8")))
@@ -96,6 +99,7 @@ class C8Loop:
         self.fuse_gru = FUSE_GRU
         self.graph = None                # one captured unit
         self.graph_n = None              # GRAPH_UNITS captured units
+        self.graph_last = None           # the final unit of a pair
         self.calibrated = not AUTOSCALE
 
     # ---- captured units -------------------------------------------------------------------------------------------
@@ -106,6 +110,10 @@ class C8Loop:
         with capture_graph(g):
             self.unit(st)
         self.graph = g
+        gl = torch.cuda.CUDAGraph()
+        with capture_graph(gl):
+            self.unit(st, last=True)
+        self.graph_last = gl
         self.graph_n = None
         if GRAPH_UNITS > 1:
             gn = torch.cuda.CUDAGraph()
@@ -114,13 +122,17 @@ class C8Loop:
                     self.unit(st)
             self.graph_n = gn
 
-    def replay(self, n):
-        """n units from the captured graphs."""
+    def replay(self, n, last=False):
+        """n units from the captured graphs (`last`: the n-th is the pair's final one)."""
+        if last:
+            n -= 1
         while self.graph_n is not None and n >= GRAPH_UNITS:
             self.graph_n.replay()
             n -= GRAPH_UNITS
         for _ in range(n):
             self.graph.replay()
+        if last:
+            self.graph_last.replay()
 
     _tail_channels = 2                   # flow (x, y) behind the 126 motion features (core/update.py:85)
 
@@ -173,8 +185,8 @@ class C8Loop:
         for _ in range(4):
             self.prologue(st)
             m = None
-            for _ in range(max(1, iters)):
-                self.unit(st)
+            for k in range(max(1, iters)):
+                self.unit(st, last=(k + 1 == max(1, iters)))
                 cur = self._maxima_dev()
                 m = cur if m is None else torch.maximum(m, cur)        # (NaN / Inf propagate: an overflow is not missed)
             overflow = self._rescale(m.cpu().tolist())
@@ -183,7 +195,7 @@ class C8Loop:
             if not overflow:
                 break
         self.calibrated = True
-        self.graph = self.graph_n = None     # (a captured unit bakes the scales in)
+        self.graph = self.graph_n = self.graph_last = None     # (a captured unit bakes the scales in)
 
     def ranges_ok(self):
         """False when a tensor's maximum has left [2^RANGE_LO, 2^RANGE_HI) under its scale (another kind of input than the one
@@ -237,11 +249,25 @@ class C8Loop:
             ds.append(c8.desc([self.rh[lvl], *xs], gru.convq, out=h, out_c8=self.hc8[lvl], epilogue=2, e0=cq, e1=z, h=h))
         c8.launch_pair(ds[0], ds[1], zs[0], _CFG["q08"])
 
+    def _fork_stem(self, ref, fn):
+        """The motion encoder's 7x7 stem beside the lookup (independent until convc2 | convf2 joins them): a third stream."""
+        if FORK < 2:
+            fn()
+            return lambda: None
+        from .update import _side_stream
+        main = torch.cuda.current_stream(ref.device)
+        side = _side_stream(ref.device, slot=1)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
+        return lambda: main.wait_stream(side)
+
     def _motion(self, st):
         enc = self.ub.encoder
+        join = self._fork_stem(st["flow"], lambda: c8.stem7_c8(st["flow"], enc.convf1, self.flo))
         if st["corr"].lookup_conv1x1(st["coords1"], enc.convc1, out_c8=self.cor) is None:
             c8.pack(st["corr"].lookup_conv1x1(st["coords1"], enc.convc1), self.cor)
-        c8.stem7_c8(st["flow"], enc.convf1, self.flo)
+        join()
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convf2, relu=True, out_c8=self.cf, out_c8_ch0=64)
         c8.launch_pair(d0, d1, st["flow"], _CFG["c2"])
@@ -266,19 +292,40 @@ class C8Loop:
         c8.interp_c8(n1, self.up1)
         c8.pool2x_c8(n1, self.pool1)
 
-    def unit(self, st):
-        self._mid(st)
-        self._motion(st)
+    def unit(self, st, last=False):
+        """Iteration i from the finest GRU on, and iteration i + 1 up to it: the middle GRU's chain of the NEXT iteration runs
+        on a second stream beside this iteration's head and the next motion encoder (round 4: these launches are a few
+        dozen microseconds each, half of it fixed cost -- unlike the wide ones they do overlap: 35.0 -> 33.0 ms per pair with
+        the fork alone).  `last`: the pair's final iteration (nothing of a next one is started)."""
         self._gru_pair(st)
-        self._head(st)
+        if last:
+            self._head(st)
+            return
+        if FORK:
+            from .update import _side_stream
+            dev = st["net"][0].device
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev, slot=0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._mid(st)
+            self._head(st)
+            self._motion(st)
+            main.wait_stream(side)
+        else:
+            self._head(st)
+            self._mid(st)
+            self._motion(st)
 
     def prologue(self, st):
-        """Per pair: hidden states into their C8S twins, then gru32 of iteration 0."""
+        """Per pair: hidden states into their C8S twins, the coarsest and the middle GRU of iteration 0 and its motion features."""
         n0, n1, n2 = st["net"]
         for lvl, n in enumerate(st["net"]):
             c8.pack(n, self.hc8[lvl])
         c8.pool2x_c8(n1, self.pool1)
         self._gru(2, self.grus[2], st, [self.pool1], 4, 4)
+        self._mid(st)
+        self._motion(st)
 
 
 class C8LoopIGEV(C8Loop):
@@ -300,10 +347,11 @@ class C8LoopIGEV(C8Loop):
     def _motion(self, st):
         enc = self.ub.encoder
         # geometry lookup + convc1 + ReLU in one kernel, straight into the C8S operand (dkt_geo_lookup_conv1x1)
+        join = self._fork_stem(st["disp"], lambda: c8.stem7_c8(st["disp"], enc.convd1, self.flo))
         if st["geo_fn"].lookup_conv1x1(st["disp"], st["coords"], enc.convc1, out_c8=self.cor) is None:
             geo = st["geo_fn"](st["disp"], st["coords"])
             c8.pack(_conv.conv2d(geo, enc.convc1, relu=True), self.cor)
-        c8.stem7_c8(st["disp"], enc.convd1, self.flo)
+        join()
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convd2, relu=True, out_c8=self.cf, out_c8_ch0=64)
         c8.launch_pair(d0, d1, st["disp"], _CFG["c2"])

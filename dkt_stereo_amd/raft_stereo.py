@@ -462,14 +462,15 @@ class RAFTStereo(nn.Module):
             lp.prologue(st)
             done = 0
             if self.c8_eager:                # (bench.py's instrumented pass: every unit as plain launches)
-                for _ in range(iters):
-                    lp.unit(st)
+                for k in range(iters):
+                    lp.unit(st, last=(k + 1 == iters))
                 done = iters
             elif lp.graph is None:
-                lp.unit(st)                  # eager once: packs weights, sizes the allocator
+                lp.unit(st, last=(iters == 1))       # eager once: packs weights, sizes the allocator
                 done = 1
                 lp.capture(st, capture_graph)        # (capturing does not execute: still one unit done)
-            lp.replay(iters - done)
+            if iters > done:
+                lp.replay(iters - done, last=True)
             # up-sampling mask head (core/update.py:107-110, :136) from the final hidden state: its 3x3 layer reads the C8S twin
             from . import conv_c8
             return .25 * conv2d(conv_c8.conv2d_c8([lp.hc8[0]], ub.mask[0], relu=True, cfg=1), ub.mask[2])
