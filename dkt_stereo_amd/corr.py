@@ -164,7 +164,7 @@ class CorrBlock1D:
     #: "skew": lookups read a diagonal-major copy of the pyramid (neighbouring pixels read
     #: neighbouring floats when disparity is locally smooth); "rows": the reference layout.
     #: Both give bit-identical results.  ``corr_pyramid`` is always the reference layout.
-    lookup_layout = os.environ.get("DKT_LOOKUP_LAYOUT", "skew")
+    lookup_layout = "skew"
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         self.num_levels = num_levels

@@ -43,9 +43,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CONV_AR
 #define CONV_AR 3
 #endif
-#ifndef CONV_ABL
-#define CONV_ABL 0        // timing-only ablation builds (tools/build_abl_variants.sh); 0 in the product
-#endif
 #ifndef CONV_MIN_BLOCKS
 #define CONV_MIN_BLOCKS 2    // blocks per CU the register budget is capped for (256 VGPRs)
 #endif
@@ -132,9 +129,7 @@ struct ConvArgsPair {
     ConvArgs p[2];
 };
 
-// ABL: timing-only ablation mask (results are wrong when non-zero): 1 = no weight loads in
-// the loop, 2 = no LDS fragment reads, 4 = no staging, 8 = no MFMAs.  See tools/bench_kernels.py.
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2, int NRM = 0>
+template <int KS, int WM, int WN, int NF, int PASSES, int MF = 2, int ST = 1, int CK = 2, int NRM = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) void conv2d_f16s_kernel(ConvArgsPair ap, int nb0) {
     // Two independent convolutions may share one launch (dkt_conv2d_f16s_pair): blocks [0, nb0) stream
     // the tiles of problem 0, the others those of problem 1 -- a small layer (the coarsest GRU: 36
@@ -540,34 +535,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
             for (int s = 0; s < NSTEP; ++s) {
                 // weights for step s+AR-1 (possibly the following chunk's first steps)
                 const int sa = s + AR - 1;
-                if (!(ABL & 1)) {
-                    if (sa < NSTEP) loadA(sa % AR, wl_cur, c, sa);
-                    else loadA(sa % AR, wl_f, c_f, sa - NSTEP);
-                }
-                if (s + 1 < NSTEP && !(ABL & 2)) loadB((s + 1) & 1, cur, s + 1);
-                if (!(ABL & 4)) {
-                    if (s < HALF) stage_load(s * PER, (s + 1) * PER);
-                    else stage_store(nxt, (s - HALF) * PER, (s - HALF + 1) * PER);
-                }
-                if (!(ABL & 8)) mma(s % AR, s & 1);
-                else {
+                if (sa < NSTEP) loadA(sa % AR, wl_cur, c, sa);
+                else loadA(sa % AR, wl_f, c_f, sa - NSTEP);
+                if (s + 1 < NSTEP) loadB((s + 1) & 1, cur, s + 1);
+                if (s < HALF) stage_load(s * PER, (s + 1) * PER);
+                else stage_store(nxt, (s - HALF) * PER, (s - HALF + 1) * PER);
+                mma(s % AR, s & 1);
 #pragma unroll
-                    for (int m = 0; m < MF; ++m) asm volatile("" ::"v"(Ahi[s % AR][m]), "v"(Alo[s % AR][m]));
-#pragma unroll
-                    for (int n = 0; n < NF; ++n) asm volatile("" ::"v"(Bhi[s & 1][n]), "v"(Blo[s & 1][n]));
-                }
-                if (!(ABL & 16)) {
-#pragma unroll
-                    for (int i = 0; i < NMMA / CONV_SGB_MFMA; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, CONV_SGB_MFMA, 0);   // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x320, CONV_SGB_MEM, 0);    // VMEM read / DS read / DS write
-                        __builtin_amdgcn_sched_group_barrier(0x002, CONV_SGB_VALU, 0);   // VALU
-                    }
+                for (int i = 0; i < NMMA / CONV_SGB_MFMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, CONV_SGB_MFMA, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x320, CONV_SGB_MEM, 0);    // VMEM read / DS read / DS write
+                    __builtin_amdgcn_sched_group_barrier(0x002, CONV_SGB_VALU, 0);   // VALU
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
-            if (more && !(ABL & 2)) loadB(0, nxt, 0);      // step 0 always uses B slot 0
+            if (more) loadB(0, nxt, 0);      // step 0 always uses B slot 0
         }
         epilogue();
         if (!have_next) break;
@@ -675,12 +658,12 @@ struct ConvSecond {
     int B;
 };
 
-template <int KS, int WM, int WN, int NF, int PASSES, int ABL = CONV_ABL, int MF = 2, int ST = 1, int CK = 2, int NRM = 0>
+template <int KS, int WM, int WN, int NF, int PASSES, int MF = 2, int ST = 1, int CK = 2, int NRM = 0>
 static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec = nullptr) {
     constexpr int NPP = ((NF * WN - 1) * ST + KS) * (31 * ST + KS);
     constexpr int STAGE = NPP * (8 * CK + 4) * (PASSES == 3 ? 2 : 1);
     const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);   // + dummy words for surplus staging lanes
-    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, ABL, MF, ST, CK, NRM>;
+    auto kern = conv2d_f16s_kernel<KS, WM, WN, NF, PASSES, MF, ST, CK, NRM>;
     // once per device and instantiation (and never inside a stream capture after warm-up)
     static int slots[64] = {0};                        // benign race: worst case computed twice
     int dev = 0;
@@ -698,8 +681,7 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec 
     const long total = (long)a.tiles_xy * a.n_co * B;
     if (total > 0x7fffffffL) return DKT_E_SHAPE;
     a.total_tiles = (int)total;
-    // DKT_CONV_PERSIST=0 (tuning knob): one block per tile, i.e. no cross-tile pipelining
-    static const bool persist = [] { const char *e = getenv("DKT_CONV_PERSIST"); return !e || atoi(e) != 0; }();
+    constexpr bool persist = true;        // blocks stream their tiles (cross-tile pipelining)
     const long cap = slots[dev & 63];
     if (!sec) {
         const long nblk = persist && total > cap ? cap : total;
@@ -750,31 +732,15 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const Con
         if constexpr (KS == 3) {
             if (sec || a.nsrc != 1 || a.epi == 1 || a.epi == 2) return DKT_E_UNSUPPORTED;
             if (a.Cout > 32 && a.Cout <= 64) {
-                if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1, 1>(a, B, st);
-                return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 2, 1, 2, 1>(a, B, st);
+                if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, 2, 1, 1, 1>(a, B, st);
+                return launch_conv<KS, 1, 4, 1, PASSES, 2, 1, 2, 1>(a, B, st);
             }
             if (a.Cout > 64 && a.Cout <= 128) {
-                if (tiles4 < CONV_FEW_TILES) return launch_conv<KS, 2, 2, 1, PASSES, CONV_ABL, 2, 1, 2, 1>(a, B, st);
-                return launch_conv<KS, 2, 2, 2, PASSES, CONV_ABL, 2, 1, 2, 1>(a, B, st);
+                if (tiles4 < CONV_FEW_TILES) return launch_conv<KS, 2, 2, 1, PASSES, 2, 1, 2, 1>(a, B, st);
+                return launch_conv<KS, 2, 2, 2, PASSES, 2, 1, 2, 1>(a, B, st);
             }
         }
         return DKT_E_UNSUPPORTED;
-    }
-    static const int forced = [] {                        // tuning knob: DKT_CONV_CFG=1|3|5|6|7|8 forces a tile shape
-        const char *e = getenv("DKT_CONV_CFG");
-        return e ? atoi(e) : 0;
-    }();
-    switch (forced) {
-    case 1: return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st, sec);
-    case 2: return launch_conv<KS, 1, 4, 2, PASSES>(a, B, st, sec);
-    case 3: return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st, sec);
-    case 5: return launch_conv<KS, 4, 1, 2, PASSES>(a, B, st, sec);
-    case 6: return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st, sec);
-    case 7: return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st, sec);
-    case 8: return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st, sec);
-    case 10: if constexpr (KS == 3) return launch_conv<KS, 4, 2, 2, PASSES>(a, B, st, sec); break;
-    case 9: if constexpr (KS == 3) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st, sec); break;
-    default: break;
     }
     // 4-row blocks keep the LDS stage at 65 KB, i.e. two blocks per CU; the 8-row forms
     // (one block per CU) measured 15-35 % slower on every encoder layer (tools/_exp_enc.py).
@@ -782,13 +748,13 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const Con
     // take half-height tiles so that twice as many CUs work.
     const long few = CONV_FEW_TILES;
     // the flow / disparity heads (2 and 1 output channels): a 32-channel wave tile halves the padded MFMA work
-    if (a.Cout <= 32) return launch_conv<KS, 1, 4, 1, PASSES, CONV_ABL, 1>(a, B, st, sec);  // 32 co x 4 rows
+    if (a.Cout <= 32) return launch_conv<KS, 1, 4, 1, PASSES, 1>(a, B, st, sec);  // 32 co x 4 rows
     if (a.Cout <= 64) {
         // 64 co x 8 rows with 16-channel chunks (33 KB LDS stage: still two blocks per CU): twice the
         // MFMAs per weight fragment of the 4-row form (64->64 @368x624: 90 -> 78 us; not for images
         // that give fewer 8-row tiles than resident blocks: @184x312 29 -> 32 us)
         if constexpr (KS == 3) {
-            if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, CONV_ABL, 2, 1, 1>(a, B, st, sec);   // >= one full wave of blocks
+            if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, 2, 1, 1>(a, B, st, sec);   // >= one full wave of blocks
         }
         return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st, sec);                          // 64 co x 4 rows
     }
@@ -813,8 +779,8 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const Con
 // 2-row output tiles keep the (2*TR+1) x 65 input patch at 52 KB per LDS stage.
 template <int KS, int PASSES>
 static int launch_conv_stride2(const ConvArgs &a, int B, hipStream_t st) {
-    if (a.Cout <= 128) return launch_conv<KS, 2, 2, 1, PASSES, CONV_ABL, 2, 2>(a, B, st);   // 128 co x 2 rows
-    return launch_conv<KS, 4, 1, 1, PASSES, CONV_ABL, 2, 2>(a, B, st);                      // 256 co x 1 row
+    if (a.Cout <= 128) return launch_conv<KS, 2, 2, 1, PASSES, 2, 2>(a, B, st);   // 128 co x 2 rows
+    return launch_conv<KS, 4, 1, 1, PASSES, 2, 2>(a, B, st);                      // 256 co x 1 row
 }
 
 // The kernel instantiations are split by number of MFMA passes so that the build can compile them as
@@ -834,16 +800,6 @@ static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hi
     if (KH == 3) return launch_conv_shape<3, PASSES>(a, B, st, sec);
     return launch_conv_shape<1, PASSES>(a, B, st, sec);
 }
-// the ablation mask each kernel translation unit was compiled with (dkt_build_ablation, abi.hip: the product is 0)
-#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 1
-int conv2d_abl_p1() { return CONV_ABL; }
-#endif
-#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 2
-int conv2d_abl_p2() { return CONV_ABL; }
-#endif
-#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 3
-int conv2d_abl_p3() { return CONV_ABL; }
-#endif
 #if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 1
 int conv2d_launch_p1(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) { return conv2d_launch_passes<1>(a, B, KH, stride, st, sec); }
 #endif

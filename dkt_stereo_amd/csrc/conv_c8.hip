@@ -28,9 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define C8_MAX_SRC 4
 #define C8_PC 34                 // patch columns: 32 + halo
-#ifndef C8_ABL
-#define C8_ABL 0                 // timing-only ablation builds (tools/c8_ablation.sh; results are wrong when non-zero):
-#endif                           // 1 no weight DMA, 2 no fragment reads, 4 no activation DMA, 8 no MFMAs, 16 no barriers, 32 no epilogue, 64 no LDS waits, 128 no Blo reads (a third of the fragment traffic)
 
 struct C8Args {
     const char *src[C8_MAX_SRC];      // C8S tensors (all with the same Hp, Wp)
@@ -99,7 +96,6 @@ __device__ __forceinline__ void c8_lds_read(f16x8 &dst, unsigned addr) {
 }
 template <int N>
 __device__ __forceinline__ void c8_wait_lgkm() {
-    if (C8_ABL & 64) return;
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 // WM x WN waves along (output channels, rows); wave tile 64 co x NF rows x 32 columns.
@@ -170,7 +166,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         return a.src[s] + (long)tb * a.src_bs[s] + (long)c * 4 * a.plane_bytes;
     };
     auto issue_act = [&](const char *base, const unsigned (&off)[NIA], int buf) {
-        if (C8_ABL & 4) return;
         char *dst = lds_act + buf * ACT_BYTES;
 #pragma unroll
         for (int j = 0; j < NIA; ++j)
@@ -186,7 +181,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
     };
     const long wstep = (long)a.n_co64 * 4096;
     auto issue_w = [&](const char *img, int slot) {
-        if (C8_ABL & 1) return;
         char *dst = lds_w + slot * WSLOT;
 #pragma unroll
         for (int j = 0; j < WPI; ++j) {
@@ -219,18 +213,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
     // not their waits, their issue).  Offsets must be literals for the asm immediates: macros, not loops.
 #define C8_MM(A, m, B, r, n)                                                                       \
     {                                                                                              \
-        if (C8_ABL & 8) asm volatile("" ::"v"(A[m]), "v"(B[r]));                                   \
-        else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[m], B[r], acc[m][n], 0, 0, 0);   \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[m], B[r], acc[m][n], 0, 0, 0);        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
 #define C8_RD(dst, off, addr)                                  \
     {                                                          \
-        if (!(C8_ABL & 2)) c8_lds_read<(off)>(dst, addr);      \
+        c8_lds_read<(off)>(dst, addr);                         \
         __builtin_amdgcn_sched_barrier(0);                     \
     }
 #define C8_RDL(dst, off, addr)                                            \
     {                                                                     \
-        if (!(C8_ABL & (2 | 128))) c8_lds_read<(off)>(dst, addr);         \
+        c8_lds_read<(off)>(dst, addr);                                    \
         __builtin_amdgcn_sched_barrier(0);                                \
     }
 #define C8_ROW(r, dx, plane) ((plane) + ((r) * C8_PC + (dx)) * 16)      /* fragment of patch row r at tap column dx */
@@ -529,7 +522,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         /* have landed once at most the pieces issued after them are outstanding                                   */ \
         if ((T) >= 1 && (T) <= C8_RING - 3) c8_wait_vm<(C8_RING - 3) * WPI + NIA>();                                   \
         else c8_wait_vm<(C8_RING - 3) * WPI>();                                                                        \
-        if (!(C8_ABL & 16)) __builtin_amdgcn_s_barrier();                                                              \
+        __builtin_amdgcn_s_barrier();                                                                                  \
         /* Alo and this step's hi rows are in; what the previous step read after them may still fly */                \
         if constexpr (DY == 0) c8_wait_lgkm<(NF > 2 ? NF - 2 : 0)>();                                                  \
         else if constexpr (DY == 1) c8_wait_lgkm<2>();                                                                 \
@@ -582,8 +575,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
             C8_STEP(0) C8_STEP(1) C8_STEP(2) C8_STEP(3) C8_STEP(4) C8_STEP(5) C8_STEP(6) C8_STEP(7) C8_STEP(8)
         }
         c8_wait_lgkm<0>();      // the prefetched fragments of the next tile have landed: their registers are stable
-        if (!(C8_ABL & 32)) epilogue();
-        else if (acc[0][0][0] == 1.2345f) a.out[0] = acc[1][NF - 1][3];
+        epilogue();
         if (!have_next) break;
         tile = tn; h0 = nh0; w0 = nw0; co_blk = nco; b = nb;
 #pragma unroll
@@ -959,4 +951,3 @@ extern "C" int dkt_conv2d_c8_head_blocks(int Cout, int cfg) {
     return DKT_E_UNSUPPORTED;
 }
 
-int conv_c8_abl() { return C8_ABL; }      // dkt_build_ablation (abi.hip)

@@ -435,8 +435,6 @@ static int conv2d_direct_impl(const float *x, long x_bstride, const float *w, co
     hipStream_t st = (hipStream_t)stream;
     if (KH == 3) {
         if (Cout > 4) return DKT_E_UNSUPPORTED;       // wide layers belong to dkt_conv2d_f16s
-        static const bool old = [] { const char *e = getenv("DKT_DIRECT_LEGACY"); return e && atoi(e) != 0; }();
-        if (old && !accumulate) return Cout <= 2 ? launch_direct<3, 2, 8>(a, B, st) : launch_direct<3, 4, 8>(a, B, st);
         if (Cout <= 1) return launch_few<1>(a, B, st);
         if (Cout <= 2) return launch_few<2>(a, B, st);
         return launch_few<4>(a, B, st);

@@ -365,17 +365,11 @@ __global__ __launch_bounds__(256) void corr1d_lookup4_kernel(LookupArgs a) {
     }
 }
 
-// Tuning knob (read per call, read-only): DKT_LOOKUP_VARIANT=1 selects the
-// one-thread-per-(pixel,level) kernel, anything else the 4-lane cooperative one.
-static int dkt_lookup_variant() {
-    const char *s = getenv("DKT_LOOKUP_VARIANT");
-    return s ? atoi(s) : 4;
-}
 
 template <int R>
 static void launch_lookup(const LookupArgs &a, int B, hipStream_t st) {
     if constexpr (2 * R + 2 <= 13) {
-        if (dkt_lookup_variant() == 4) {
+        {
             dim3 grid((unsigned)((a.HW + 63) / 64), (unsigned)a.L, (unsigned)B);
             hipLaunchKernelGGL(corr1d_lookup4_kernel<R>, grid, dim3(256), 0, st, a);
             return;

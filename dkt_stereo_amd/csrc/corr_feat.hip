@@ -609,9 +609,8 @@ static int corr_feat_impl(const float *const *skew, const float *coords_x, long 
     a.out_c8_Wp = Wp; a.out_c8_ch0 = out_c8_ch0; a.act_scale = act_scale;
     DKT_ENTER(device);
     hipStream_t st = (hipStream_t)stream;
-    // four levels: the block form (64-pixel segments); DKT_CORR_FEAT_PX=16 keeps the quarter-wave form
-    static const bool px16 = [] { const char *e = getenv("DKT_CORR_FEAT_PX"); return e && atoi(e) == 16; }();
-    if (L == 4 && !px16) {
+    // four levels: the block form (64-pixel segments)
+    if (L == 4) {
         const long blocks = (long)H * ((W1 + 63) / 64);
         if (blocks > 0x7fffffffL) return DKT_E_SHAPE;
         dim3 grid((unsigned)blocks, (unsigned)B);
@@ -620,9 +619,6 @@ static int corr_feat_impl(const float *const *skew, const float *coords_x, long 
         return dkt_launch_status();
     }
     if (out_c8) return r == 4 ? cf16_launch<4>(a, B, st) : cf16_launch<3>(a, B, st);
-    // four levels: the 16-pixel form (one level per quarter-wave); DKT_CORR_FEAT_PX=32 forces the half-wave form
-    static const bool px32 = [] { const char *e = getenv("DKT_CORR_FEAT_PX"); return e && atoi(e) == 32; }();
-    if (L == 4 && !px32) return r == 4 ? cf16_launch<4>(a, B, st) : cf16_launch<3>(a, B, st);
     if (r == 4) {
         if (L == 4) return cf_launch<4, 4>(a, B, st);
         if (L == 3) return cf_launch<3, 4>(a, B, st);

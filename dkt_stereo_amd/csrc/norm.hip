@@ -474,9 +474,8 @@ extern "C" int dkt_interp_bilinear(const float *x, float *y, long planes, int H,
     const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.0f;
     // up-sampling with 16-byte aligned rows: the LDS-staged form.  INTERP_RB output rows blend at most
     // floor((INTERP_RB - 1) * sy) + 3 source rows.
-    static const bool gather_only = [] { const char *e = getenv("DKT_INTERP_LEGACY"); return e && atoi(e) != 0; }();
     const long nblk = planes * ((Ho + INTERP_RB - 1) / INTERP_RB);
-    if (!gather_only && W % 4 == 0 && Wo % 4 == 0 && W <= INTERP_MAXW && sy <= 1.0f && sx <= 1.0f
+    if (W % 4 == 0 && Wo % 4 == 0 && W <= INTERP_MAXW && sy <= 1.0f && sx <= 1.0f
         && (int)((INTERP_RB - 1) * sy) + 3 <= INTERP_SR && nblk <= 0x7fffffffL
         && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
         hipLaunchKernelGGL(interp_lds_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, y, H, W, Ho, Wo, sy, sx);

@@ -385,8 +385,7 @@ extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
         if (e != hipSuccess) return (int)e;
     }
     const bool vec16 = W % 4 == 0 && vol_bstride % 4 == 0 && ((((uintptr_t)vol) | ((uintptr_t)ref) | ((uintptr_t)tgt)) & 15) == 0;
-    static const bool big_legacy = [] { const char *e = getenv("DKT_GWC_LEGACY"); return e && atoi(e) != 0; }();
-    if (big && vec16 && !big_legacy && (long)((W + 3) / 4) * ((D + 3) / 4) <= 256L * GWC_NI) {
+    if (big && vec16 && (long)((W + 3) / 4) * ((D + 3) / 4) <= 256L * GWC_NI) {
         const int lpad_c = ((D + 3) & ~3) + 4;
         const size_t lds_c = (size_t)GWC_CH * (lpad_c + 2 * ((W + 7) & ~3)) * sizeof(float);
         if (lds_c <= 64 * 1024) {
@@ -402,14 +401,13 @@ extern "C" int dkt_gwc_volume(const float *ref, const float *tgt, float *vol,
     else {
         // float4 plane stores need 16-byte aligned rows: W and the batch stride multiples of 4, aligned base
         const bool vec = W % 4 == 0 && vol_bstride % 4 == 0 && ((uintptr_t)vol & 15) == 0;
-        static const bool legacy = [] { const char *e = getenv("DKT_GWC_LEGACY"); return e && atoi(e) != 0; }();
         const int lpad = ((D + 3) & ~3) + 4;
         const int rp = (W + 7) & ~3;
         const size_t lds_q = (size_t)cpg * (lpad + 2 * rp) * sizeof(float);
         dim3 grid((unsigned)blocks), blk(256);
         hipStream_t st = (hipStream_t)stream;
 
-        if (legacy || lds_q > 64 * 1024)
+        if (lds_q > 64 * 1024)
             hipLaunchKernelGGL(gwc_volume_kernel, grid, blk, lds, st, ref, tgt, vol, C, H, W, D, G, vol_bstride);
         else if (vec)
             hipLaunchKernelGGL(gwc_volume_quad_kernel<true>, grid, blk, lds_q, st, ref, tgt, vol, C, H, W, D, G, vol_bstride, lpad);

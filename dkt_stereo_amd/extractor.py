@@ -32,9 +32,9 @@ CNET_STREAMS = os.environ.get("DKT_CNET_STREAMS", "1") != "0"
 #: cnet (profiles/r03_encoder_c8.txt)
 C8_ENCODER = os.environ.get("DKT_C8_ENCODER", "0") == "1"
 #: full-resolution pixels from which layer1 takes the C8S path (its tiles are 8 rows x 32 columns; smaller images leave CUs idle)
-C8_ENCODER_MIN_PIXELS = int(os.environ.get("DKT_C8_ENCODER_MIN_PIXELS", "100000"))
+C8_ENCODER_MIN_PIXELS = 100000
 #: tile shape of the 64 -> 64 layers (conv_c8.hip c8_dispatch)
-C8_ENCODER_CFG = int(os.environ.get("DKT_C8_ENCODER_CFG", "3"))
+C8_ENCODER_CFG = 3
 
 
 def _hip_ok(x):

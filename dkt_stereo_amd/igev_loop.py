@@ -24,7 +24,7 @@ from .conv import conv2d
 from .update import FUSE_GATES, GPU_GUARD, _side_stream, capture_graph, gru_pair, harness, interp, pool2x, replay_graph
 
 #: the coarsest GRU of the next iteration shares the finest GRU's two launches (dkt_conv2d_f16s_pair)
-PAIR_GRUS = os.environ.get("DKT_PAIR_GRUS", "1") != "0"
+PAIR_GRUS = True
 
 
 def _plain(update_block, geo_fn, disp, coords, net_list, inp_list, iters):
@@ -121,10 +121,10 @@ def _body(ub, st, need_mask, last):
 # ---- rotated schedule (as raft_stereo.RAFTStereo._iterate_rotated): the captured unit is
 #   { middle GRU (i) on the side stream  ||  disparity head (i-1), geometry lookup (i), motion encoder (i) }  ->
 #   finest GRU (i) + coarsest GRU (i+1) in shared launches
-# -- the middle GRU of an iteration needs the finest state of the PREVIOUS one only.  Opt-in here (DKT_ROTATE_IGEV=1):
+# -- the middle GRU of an iteration needs the finest state of the PREVIOUS one only.  Opt-in here (the module attribute ROTATE):
 # measured no gain on the IGEV loop (32.4 ms either way at cfg3 -- its geometry lookup and 162-channel motion
 # encoder already cover the middle GRU), so the default stays the schedule of _body.
-ROTATE = os.environ.get("DKT_ROTATE_IGEV", "0") == "1"
+ROTATE = False
 
 
 def _mid(ub, nets, inp, hold):

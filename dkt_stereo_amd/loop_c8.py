@@ -18,12 +18,10 @@ from . import conv as _conv
 from . import conv_c8 as c8
 from .update import interp, pool2x, _leading_outputs
 
-#: tile shapes (conv_c8.hip c8_dispatch) per layer class; DKT_C8_CFG="zr08,q08,zr16,q16,head,enc,c2" overrides
+#: tile shapes (conv_c8.hip c8_dispatch) per layer class
 _CFG = dict(zr08=1, q08=2, zr16=4, q16=4, head=2, enc=3, c2=3)
-#: flow head with the hidden tensor reduced in conv1's epilogue (DKT_C8_FUSE_HEAD=0: hidden tensor + few-output kernel)
-FUSE_HEAD = os.environ.get("DKT_C8_FUSE_HEAD", "1") != "0"
-if os.environ.get("DKT_C8_CFG"):
-    _CFG.update(zip(("zr08", "q08", "zr16", "q16", "head", "enc", "c2"), (int(v) for v in os.environ["DKT_C8_CFG"].split(","))))
+#: flow head with the hidden tensor reduced in conv1's epilogue (FUSE_HEAD = False: hidden tensor + few-output kernel)
+FUSE_HEAD = True
 
 
 #: round 4: the finest GRU (with the coarsest one of the next iteration riding along) as ONE launch per step (csrc/gru_c8.hip:

@@ -109,9 +109,9 @@ class RAFTStereo(nn.Module):
 
     #: replay the encoder pass (normalisation, fnet || cnet, context split: ~110 launches, two streams) from a
     #: captured HIP graph as well: launched eagerly, the host needs 2.5 ms to enqueue fnet before cnet's first
-    #: kernel can start, and ~0.3 ms of launch gaps precede the first convolution.  Opt-in (DKT_ENCODER_GRAPH=1): at
+    #: kernel can start, and ~0.3 ms of launch gaps precede the first convolution.  Opt-in (attribute graph_encoders): at
     #: 736x1248 the encoders are GPU-bound and the replay measured no faster (9.63 vs 9.45 ms); it pays on small images
-    graph_encoders = os.environ.get("DKT_ENCODER_GRAPH", "0") == "1"
+    graph_encoders = False
 
     def _encoder_fingerprint(self):
         fp = [(_conv.get_backend(), _extractor.FUSE_ENCODER, self.encoder_streams)]
@@ -259,18 +259,18 @@ class RAFTStereo(nn.Module):
                 dst.copy_(src)
         return up_mask
 
-    #: software-pipeline the GRU stack across iterations (DKT_PIPELINE_GRUS=0 disables): gru16 of
+    #: software-pipeline the GRU stack across iterations (attribute pipeline_grus): gru16 of
     #: this iteration and gru32 of the NEXT one run on a second stream beside lookup + motion
     #: encoder + gru08 + flow head.  Every GRU still sees exactly the inputs the reference's
     #: sequential order gives it (gru32(i+1) needs only net[2](i), net[1](i)): bit-identical.
-    pipeline_grus = os.environ.get("DKT_PIPELINE_GRUS", "1") != "0"
+    pipeline_grus = True
     #: with the pipelined schedule: the motion encoder's flow branch on a third stream.  Opt-in
-    #: (DKT_BRANCH_STREAMS=1): measured gain 0.3 ms per pair, not worth a third capture branch by default
-    branch_streams = os.environ.get("DKT_BRANCH_STREAMS", "0") == "1"
+    #: (attribute branch_streams): measured gain 0.3 ms per pair, not worth a third capture branch by default
+    branch_streams = False
 
     #: with the pipelined schedule: gru32 of the next iteration shares the two launches of gru08
-    #: (dkt_conv2d_f16s_pair; DKT_PAIR_GRUS=0 keeps it as launches of its own on the side stream)
-    pair_grus = os.environ.get("DKT_PAIR_GRUS", "1") != "0"
+    #: (dkt_conv2d_f16s_pair; pair_grus = False keeps it as launches of its own on the side stream)
+    pair_grus = True
 
     def _can_pipeline(self):
         a = self.args
@@ -338,13 +338,13 @@ class RAFTStereo(nn.Module):
                 dst.copy_(src)
         return up_mask
 
-    #: rotated software pipeline (DKT_ROTATE=0: the schedule of _one_iteration_pipelined).  The captured unit is
+    #: rotated software pipeline (rotate = False: the schedule of _one_iteration_pipelined).  The captured unit is
     #: not "iteration i" but  { gru16(i) on the side stream  ||  flow head(i-1), lookup(i), motion encoder(i) } ->
     #: gru08(i) + gru32(i+1) : the middle GRU of an iteration only needs the finest state of the PREVIOUS one, so
     #: it runs beside the previous iteration's flow head instead of in front of this iteration's finest GRU
     #: (trace: gru08 waited ~100 us per iteration for the gru16 chain).  Same operations on the same operands in
     #: an order the reference's data dependencies allow: bit-identical.
-    rotate = os.environ.get("DKT_ROTATE", "1") != "0"
+    rotate = True
 
     def _stage_mid(self, nets, inp, hold):
         """gru16 of the coming iteration + the two resampled copies of its result the other GRUs consume."""
@@ -373,8 +373,8 @@ class RAFTStereo(nn.Module):
         nets[0], nets[2] = gru_pair(ub.gru08, (nets[0], *inp[0], [mf, hold["up16"]], nets[0]),
                                     ub.gru32, (nets[2], *inp[2], [hold["pool16"]], nets[2]))
 
-    #: the rotated loop computes only the x output of flow_head.conv2 (DKT_HEAD_X_ONLY=0: both, y dropped afterwards)
-    head_x_only = os.environ.get("DKT_HEAD_X_ONLY", "1") != "0"
+    #: the rotated loop computes only the x output of flow_head.conv2 (head_x_only = False: both, y dropped afterwards)
+    head_x_only = True
 
     def _stage_head(self, nets, coords1, need_mask, coords0=None, flow=None):
         ub = self.update_block

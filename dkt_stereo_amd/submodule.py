@@ -25,9 +25,9 @@ def _check_pair(ref, tgt):
 
 
 #: "mfma": the banded matrix product on the exact-fp32 matrix cores (dkt_gwc_volume_mfma) where it applies, else the VALU
-#: kernel; "exact": always the VALU kernel, bit-identical to the C restatement's summation order.  DKT_GWC=exact|mfma.
+#: kernel; "exact": always the VALU kernel, bit-identical to the C restatement's summation order.  (submodule.gwc_mode(...) switches.)
 import os as _os
-GWC_MODE = _os.environ.get("DKT_GWC", "mfma")
+GWC_MODE = "mfma"
 
 
 import contextlib as _contextlib

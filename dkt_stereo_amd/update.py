@@ -14,7 +14,7 @@ What differs from the reference is how a GRU step is evaluated (core/update.py:2
   * default path: the gate arithmetic lives in the convolution epilogues
     (dkt_conv2d_f16s_gate_zr / _gate_out): two launches per GRU, no z|r / q pre-activation
     tensors, and the reference's torch.cat operands are read in place;
-  * DKT_FUSE_GATES=0 or the vendor-convolution backend: two streaming gate kernels
+  * FUSE_GATES = False or the vendor-convolution backend: two streaming gate kernels
     (dkt_gru_gate_zr / _out) after the convolutions instead of ~12 elementwise launches.
 Convolutions go through ``dkt_stereo_amd.conv.conv2d`` (see that module).
 Inference only.
@@ -134,11 +134,11 @@ def harness(**switches):
 
 #: evaluate the GRU gates inside the convolution epilogues (dkt_conv2d_f16s_gate_zr/_out)
 #: instead of the two streaming gate kernels
-FUSE_GATES = os.environ.get("DKT_FUSE_GATES", "1") != "0"
+FUSE_GATES = True
 
 
 #: the motion encoder's two independent 64 -> 64 layers (convc2, convf2 / convd2) share one launch
-PAIR_ENCODER = os.environ.get("DKT_PAIR_ENCODER", "1") != "0"
+PAIR_ENCODER = True
 
 
 def _batch_dense(t, hw):
@@ -493,9 +493,9 @@ class BasicMultiUpdateBlock(nn.Module):
             nn.ReLU(inplace=True),
             nn.Conv2d(256, (factor ** 2) * 9, 1, padding=0))
 
-    #: run the motion encoder concurrently with gru32/gru16 on a second stream (DKT_SIDE_STREAM=0 disables);
+    #: run the motion encoder concurrently with gru32/gru16 on a second stream (attribute side_stream);
     #: a harness that forks / joins itself overrides it per thread with harness(side_stream=False)
-    side_stream = os.environ.get("DKT_SIDE_STREAM", "1") != "0"
+    side_stream = True
     # Other per-thread harness switches (see _Harness): inplace_state -- GRUs overwrite their hidden-state
     # tensors (the reference rebinds net[i] to a fresh tensor; nothing else may hold the old one);
     # before_fine -- hook between the motion encoder and the finest GRU.

@@ -48,9 +48,6 @@ enum {
 #define DKT_MAX_RADIUS 8
 
 int dkt_version(void);
-/* 0 for a product build; non-zero = a timing-only ablation build of the convolution kernels (wrong results by construction;
- * tools/c8_ablation.sh, tools/build_abl_variants.sh).  Host-only: callable without a device. */
-int dkt_build_ablation(void);
 const char *dkt_strerror(int rc);
 
 /* ---- RAFT-Stereo 1-D correlation --------------------------------------- */
