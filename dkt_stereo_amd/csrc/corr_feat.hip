@@ -411,7 +411,10 @@ __global__ __launch_bounds__(256) void corr_feat16_kernel(CorrFeatArgs a) {
 // pixels (lane = pixel: every window load of the wave is one 256-byte segment of the skewed pyramid -- the 16-pixel form
 // moves the same bytes in 64-byte pieces) and leaves its K values per pixel in LDS.  Phase 2: wave m multiplies the
 // 36 x 64 sample matrix with output channels 16m .. 16m+15 on v_mfma_f32_16x16x4_f32 (k ascending: level-major) and
-// stores them -- C8S: 256 contiguous bytes per 16-pixel tile and half.  At cfg4's batch 8: 76 -> see DESIGN 3.3.
+// stores them -- C8S: 256 contiguous bytes per 16-pixel tile and half.  At cfg4's batch 8: 76 -> 62 us, DESIGN 3.3.
+// (Round 4 tried two segments per block, software-pipelined -- segment 1's window loads in flight under segment 0's MFMAs and
+// stores, weights fetched once: 70 us against 62 at B = 8.  Fewer, longer blocks lose more latency hiding than the pipelining
+// inside one block wins; not kept.)
 template <int R>
 __global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
     constexpr int K = 2 * R + 1;
