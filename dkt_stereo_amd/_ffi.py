@@ -64,8 +64,16 @@ class GruC8Desc(ctypes.Structure):
                 ("flags", ctypes.c_void_p)]
 
 
+class ResampleC8Job(ctypes.Structure):
+    """dkt_resample_c8_job of include/dktstereo.h."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_bstride", ctypes.c_long), ("dst", ctypes.c_void_p), ("dst_bstride_bytes", ctypes.c_long),
+                ("B", ctypes.c_int), ("C", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Ho", ctypes.c_int),
+                ("Wo", ctypes.c_int), ("ch0", ctypes.c_int), ("kind", ctypes.c_int), ("scale", ctypes.c_float)]
+
+
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
+    "dkt_resample_pair_c8": [ctypes.POINTER(ResampleC8Job), ctypes.POINTER(ResampleC8Job), _i, _vp],
     "dkt_gru_c8_flag_words": [_i, _i, _i],
     "dkt_conv2d_stats_ws_floats": [_i, _i, _i, _i],
     "dkt_gru_c8": [ctypes.POINTER(GruC8Desc), _vp, _i, _vp],

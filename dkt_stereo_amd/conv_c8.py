@@ -369,6 +369,27 @@ def interp_c8(x, dst, ch0=0):
     return dst
 
 
+def _resample_job(kind, x, dst, ch0):
+    B, C, H, W = x.shape
+    return _ffi.ResampleC8Job(x=x.data_ptr(), x_bstride=x.stride(0), dst=dst.data_ptr(), dst_bstride_bytes=dst.bstride_bytes,
+                              B=B, C=C, H=H, W=W, Ho=dst.H, Wo=dst.W, ch0=ch0, kind=kind, scale=dst.scale)
+
+
+def resample_pair_c8(job0, job1):
+    """Two resampling jobs in one launch (dkt_resample_pair_c8); a job = ("pool" | "interp", x, dst[, ch0]): pool2x_c8 /
+    interp_c8 of x into dst.  Bit-identical to the single launches."""
+    jobs = []
+    for kind, x, dst, *rest in (job0, job1):
+        if kind == "pool" and (dst.H, dst.W) != ((x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1):
+            raise ValueError("resample_pair_c8: pool2x destination is %dx%d for a %dx%d source" % (dst.H, dst.W, x.shape[2], x.shape[3]))
+        if x.shape[0] != dst.B or (rest[0] if rest else 0) + x.shape[1] > 8 * dst.t.shape[1]:
+            raise ValueError("resample_pair_c8: the destination does not hold the job's batch / channels")
+        jobs.append(_resample_job(0 if kind == "pool" else 1, x, dst, rest[0] if rest else 0))
+    x0 = job0[1]
+    rc = _ffi.lib().dkt_resample_pair_c8(ctypes.byref(jobs[0]), ctypes.byref(jobs[1]), _ffi.device_of(x0), _ffi.stream_of(x0))
+    _ffi.check(rc, "dkt_resample_pair_c8")
+
+
 def stem7_c8(x, layer, dst, relu=True, ch0=0):
     """dst[ch0 : ...] = C8S([relu](conv7x7(x))) for the 2- / 1-channel stems (core/update.py:75)."""
     from . import conv as _conv

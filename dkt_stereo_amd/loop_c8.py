@@ -39,6 +39,10 @@ RANGE_LO, RANGE_HI = 6, 14
 #: the middle GRU's chain of the next iteration on a second stream beside the head and the motion encoder (DKT_C8_FORK=0: one stream)
 #: (=2: also the motion encoder's 7x7 stem beside the lookup on a third stream -- measured 0.25 ms per pair SLOWER, kept for A/B)
 FORK = int(os.environ.get("DKT_C8_FORK", "1"))
+#: the two resampling jobs in front of / behind the middle GRU as one launch each (dkt_resample_pair_c8)
+PAIR_RESAMPLE = True
+#: the flow head is the fused GRU launch's first successor in the captured unit (see C8Loop.unit)
+HEAD_FIRST = True
 #: units per captured graph: a replay boundary costs ~8 us of idle device between two units (profiles/r04_pair_breakdown.txt), so
 #: the bulk of the iterations is replayed GRAPH_UNITS units at a time (a one-unit graph serves the remainder)
 GRAPH_UNITS = max(1, int(os.environ.get("DKT_C8_GRAPH_UNITS", "8")))
@@ -284,11 +288,17 @@ class C8Loop:
 
     def _mid(self, st):
         n0, n1, n2 = st["net"]
-        c8.pool2x_c8(n0, self.pool0)
-        c8.interp_c8(n2, self.up2)
+        if PAIR_RESAMPLE:
+            c8.resample_pair_c8(("pool", n0, self.pool0), ("interp", n2, self.up2))
+        else:
+            c8.pool2x_c8(n0, self.pool0)
+            c8.interp_c8(n2, self.up2)
         self._gru(1, self.grus[1], st, [self.pool0, self.up2], _CFG["zr16"], _CFG["q16"])
-        c8.interp_c8(n1, self.up1)
-        c8.pool2x_c8(n1, self.pool1)
+        if PAIR_RESAMPLE:
+            c8.resample_pair_c8(("interp", n1, self.up1), ("pool", n1, self.pool1))
+        else:
+            c8.interp_c8(n1, self.up1)
+            c8.pool2x_c8(n1, self.pool1)
 
     def unit(self, st, last=False):
         """Iteration i from the finest GRU on, and iteration i + 1 up to it: the middle GRU's chain of the NEXT iteration runs
@@ -304,10 +314,20 @@ class C8Loop:
             dev = st["net"][0].device
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev, slot=0)
-            side.wait_stream(main)
+            if HEAD_FIRST:
+                # the head is enqueued BEFORE the forked chain: in the instantiated graph the fused GRU launch's first
+                # successor stays on its queue, so the critical chain gru -> head -> motion encoder -> gru crosses no queue
+                # boundary (a cross-queue dependency costs ~10 us of idle device, twice per iteration)
+                forked = torch.cuda.Event()
+                forked.record(main)
+                self._head(st)
+                side.wait_event(forked)
+            else:
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._mid(st)
-            self._head(st)
+            if not HEAD_FIRST:
+                self._head(st)
             self._motion(st)
             main.wait_stream(side)
         else:

@@ -518,6 +518,16 @@ int dkt_pool2x_c8(const float *x, long x_bstride, void *dst, long dst_bstride_by
                   int ch0, float scale, int device, void *stream);
 int dkt_interp_c8(const float *x, long x_bstride, void *dst, long dst_bstride_bytes, int B, int C, int H, int W,
                   int Ho, int Wo, int ch0, float scale, int device, void *stream);
+/* two of the resampling jobs above in one launch (round 4: the loop's pool2x(net[0]) | interp(net[2]) in front of the
+ * middle ConvGRU and interp(net[1]) | pool2x(net[1]) behind it, core/update.py:120-132); kind 0 = pool2x (Ho, Wo ignored),
+ * kind 1 = interp to (Ho, Wo).  Same arithmetic as the single launches. */
+typedef struct dkt_resample_c8_job {
+    const float *x; long x_bstride;             /* fp32 NCHW source (B, C, H, W), batch stride in floats */
+    void *dst; long dst_bstride_bytes;          /* C8S destination */
+    int B, C, H, W, Ho, Wo, ch0, kind;
+    float scale;                                /* the destination's power-of-two scale */
+} dkt_resample_c8_job;
+int dkt_resample_pair_c8(const dkt_resample_c8_job *job0, const dkt_resample_c8_job *job1, int device, void *stream);
 int dkt_conv2d_stem7_c8(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
                         const float *bias, float out_scale, float in_scale, void *y_c8, long y_c8_bstride_bytes,
                         int y_c8_ch0, float act_scale, int B, int Cin, int Cout, int H, int W, int relu,

@@ -253,3 +253,31 @@ def test_conv_epilogue_statistics_match_the_statistics_pass(shape):
     assert float((got[:, 0].double() - mean).abs().max()) <= 2e-6 * scale
     assert float((got[:, 1].double() / invstd - 1).abs().max()) <= 2e-6
     assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 46, 78), (2, 33, 37), (1, 92, 156)])
+def test_resample_pair_equals_single_launches(B, H, W):
+    """dkt_resample_pair_c8 (pool2x | interp in one launch, core/update.py:87-95) writes the bytes of the two single launches;
+    jobs of different sizes, either order, a scaled destination; shape errors are refused."""
+    c8 = _c8()
+    torch.manual_seed(H)
+    fine = torch.randn(B, 128, 2 * H, 2 * W - 1, device=DEV)
+    coarse = torch.randn(B, 128, (H + 1) // 2, (W + 1) // 2, device=DEV)
+    Hm, Wm = (fine.shape[2] - 1) // 2 + 1, (fine.shape[3] - 1) // 2 + 1
+
+    def fresh(scale):
+        a, b = c8.ActC8(B, 128, Hm, Wm, DEV), c8.ActC8(B, 128, Hm, Wm, DEV)
+        a.scale = b.scale = scale
+        return a, b
+
+    for scale in (1.0, 64.0):
+        p0, u0 = fresh(scale)
+        c8.pool2x_c8(fine, p0)
+        c8.interp_c8(coarse, u0)
+        for order in (0, 1):
+            p1, u1 = fresh(scale)
+            jobs = [("pool", fine, p1), ("interp", coarse, u1)]
+            c8.resample_pair_c8(*(jobs if order == 0 else jobs[::-1]))
+            assert torch.equal(p0.t, p1.t) and torch.equal(u0.t, u1.t)
+    with pytest.raises(ValueError):
+        c8.resample_pair_c8(("pool", fine, c8.ActC8(B, 128, Hm + 1, Wm, DEV)), ("interp", coarse, u0))
