@@ -64,6 +64,27 @@ class GruC8Desc(ctypes.Structure):
                 ("flags", ctypes.c_void_p)]
 
 
+class MotionFrontDesc(ctypes.Structure):
+    """dkt_motion_front_desc of include/dktstereo.h."""
+    _fields_ = [("skew", ctypes.POINTER(ctypes.c_void_p)),
+                ("planes", ctypes.c_void_p), ("planes_bstride", ctypes.c_long), ("n_co", ctypes.c_int),
+                ("head_bias", ctypes.c_void_p),
+                ("x_old", ctypes.c_void_p), ("x_old_bstride", ctypes.c_long),
+                ("x_new", ctypes.c_void_p), ("x_new_bstride", ctypes.c_long),
+                ("x0", ctypes.c_void_p), ("x0_bstride", ctypes.c_long),
+                ("flow", ctypes.c_void_p), ("flow_bstride", ctypes.c_long),
+                ("w_cor", ctypes.c_void_p), ("b_cor", ctypes.c_void_p), ("cor_channels", ctypes.c_int),
+                ("cor_c8", ctypes.c_void_p), ("cor_c8_bstride_bytes", ctypes.c_long), ("cor_c8_ch0", ctypes.c_int),
+                ("cor_act_scale", ctypes.c_float),
+                ("stem_w_hi", ctypes.c_void_p), ("stem_w_lo", ctypes.c_void_p), ("stem_bias", ctypes.c_void_p),
+                ("stem_out_scale", ctypes.c_float), ("stem_in_scale", ctypes.c_float), ("stem_cin", ctypes.c_int),
+                ("stem_cout", ctypes.c_int),
+                ("flo_c8", ctypes.c_void_p), ("flo_c8_bstride_bytes", ctypes.c_long), ("flo_c8_ch0", ctypes.c_int),
+                ("flo_act_scale", ctypes.c_float),
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("W1", ctypes.c_int), ("W2", ctypes.c_int), ("L", ctypes.c_int),
+                ("r", ctypes.c_int)]
+
+
 class ResampleC8Job(ctypes.Structure):
     """dkt_resample_c8_job of include/dktstereo.h."""
     _fields_ = [("x", ctypes.c_void_p), ("x_bstride", ctypes.c_long), ("dst", ctypes.c_void_p), ("dst_bstride_bytes", ctypes.c_long),
@@ -73,6 +94,7 @@ class ResampleC8Job(ctypes.Structure):
 
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
+    "dkt_motion_front_c8": [ctypes.POINTER(MotionFrontDesc), _i, _vp],
     "dkt_resample_pair_c8": [ctypes.POINTER(ResampleC8Job), ctypes.POINTER(ResampleC8Job), _i, _vp],
     "dkt_gru_c8_flag_words": [_i, _i, _i],
     "dkt_conv2d_stats_ws_floats": [_i, _i, _i, _i],

@@ -66,12 +66,21 @@ class ActC8:
         return self.t.device
 
 
+def _check_dst(what, dst, B, C, H, W, ch0=0):
+    """The C8S producers write (B, [ch0, ch0 + C), H, W) of `dst` and derive its plane geometry from (H, W): a destination
+    of another shape, or with fewer (padded) channels, would be written out of bounds."""
+    if (dst.B, dst.H, dst.W) != (B, H, W) or (ch0 & 7) or ch0 < 0 or ch0 + C > 8 * dst.t.shape[1]:
+        raise ValueError("%s: destination is (B=%d, %d padded channels, %dx%d), the result (B=%d, channels %d..%d, %dx%d)"
+                         % (what, dst.B, 8 * dst.t.shape[1], dst.H, dst.W, B, ch0, ch0 + C - 1, H, W))
+
+
 def pack(x, dst=None, ch0=0, scale=None):
     """fp32 NCHW -> channels [ch0, ch0 + C) of an ActC8 (a new one of exactly C channels by default)."""
     _ffi.require_gpu(x)
     B, C, H, W = x.shape
     if dst is None:
         dst = ActC8(B, C, H, W, x.device, 1.0 if scale is None else scale)
+    _check_dst("conv_c8.pack", dst, B, C, H, W, ch0)
     x = x if (x.stride(3) == 1 and x.stride(2) == W and x.stride(1) == H * W) else x.contiguous()
     rc = _ffi.lib().dkt_act_c8_pack(x.data_ptr(), x.stride(0), dst.data_ptr(), dst.bstride_bytes, B, C, H, W, ch0,
                                     dst.scale, _ffi.device_of(x), _ffi.stream_of(x))
@@ -354,6 +363,7 @@ def gate_out(srcs, q_layer, cq, z, h, out, out_c8=None, cfg=0, f32_c4=False):
 def pool2x_c8(x, dst, ch0=0):
     """dst[ch0 : ch0 + C] = C8S(avg_pool2d(x, 3, stride=2, padding=1)) (core/update.py:87-88), x fp32 NCHW dense per batch."""
     B, C, H, W = x.shape
+    _check_dst("pool2x_c8", dst, B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, ch0)
     rc = _ffi.lib().dkt_pool2x_c8(x.data_ptr(), x.stride(0), dst.data_ptr(), dst.bstride_bytes, B, C, H, W, ch0, dst.scale,
                                   _ffi.device_of(x), _ffi.stream_of(x))
     _ffi.check(rc, "dkt_pool2x_c8")
@@ -363,6 +373,7 @@ def pool2x_c8(x, dst, ch0=0):
 def interp_c8(x, dst, ch0=0):
     """dst[ch0 : ch0 + C] = C8S(F.interpolate(x, (dst.H, dst.W), mode="bilinear", align_corners=True)) (core/update.py:93-95)."""
     B, C, H, W = x.shape
+    _check_dst("interp_c8", dst, B, C, dst.H, dst.W, ch0)
     rc = _ffi.lib().dkt_interp_c8(x.data_ptr(), x.stride(0), dst.data_ptr(), dst.bstride_bytes, B, C, H, W, dst.H, dst.W, ch0,
                                   dst.scale, _ffi.device_of(x), _ffi.stream_of(x))
     _ffi.check(rc, "dkt_interp_c8")
@@ -382,8 +393,7 @@ def resample_pair_c8(job0, job1):
     for kind, x, dst, *rest in (job0, job1):
         if kind == "pool" and (dst.H, dst.W) != ((x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1):
             raise ValueError("resample_pair_c8: pool2x destination is %dx%d for a %dx%d source" % (dst.H, dst.W, x.shape[2], x.shape[3]))
-        if x.shape[0] != dst.B or (rest[0] if rest else 0) + x.shape[1] > 8 * dst.t.shape[1]:
-            raise ValueError("resample_pair_c8: the destination does not hold the job's batch / channels")
+        _check_dst("resample_pair_c8", dst, x.shape[0], x.shape[1], dst.H, dst.W, rest[0] if rest else 0)
         jobs.append(_resample_job(0 if kind == "pool" else 1, x, dst, rest[0] if rest else 0))
     x0 = job0[1]
     rc = _ffi.lib().dkt_resample_pair_c8(ctypes.byref(jobs[0]), ctypes.byref(jobs[1]), _ffi.device_of(x0), _ffi.stream_of(x0))
@@ -400,6 +410,9 @@ def stem7_c8(x, layer, dst, relu=True, ch0=0):
     with _CACHE_LOCK:
         pk = _conv._stem7_packed(layer, key, L)
     in_scale = 2.0 ** _conv.in_exp_of(layer)
+    if int(w.shape[0]) % 64:
+        raise ValueError("stem7_c8: the C8S store writes whole 64-channel blocks (layer has %d outputs)" % int(w.shape[0]))
+    _check_dst("stem7_c8", dst, B, int(w.shape[0]), H, W, ch0)
     rc = L.dkt_conv2d_stem7_c8(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
                                None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale / in_scale, in_scale,
                                dst.data_ptr(), dst.bstride_bytes, ch0, dst.scale, B, cin, int(w.shape[0]), H, W, int(bool(relu)),
@@ -422,20 +435,79 @@ def _head_weights(layer2):
         return hit[1]
 
 
-def head(srcs, layer1, layer2, target, diff=None, cfg=2):
-    """target += layer2(relu(layer1(cat(srcs)))) for the flow / disparity head (core/update.py:6-14; raft_stereo.py:165-168),
-    `layer2` a 3x3 layer with 1 or 2 outputs: the hidden tensor is never written -- layer1's epilogue reduces it against
-    layer2's weights tap by tap (epilogue 3), dkt_head_finish adds the shifted planes.  diff = (ref, dst): dst = target - ref."""
+def head_planes(srcs, layer1, layer2, cfg=2):
+    """First half of `head`: layer1 with the per-tap projections against layer2's weights in its epilogue (epilogue 3).
+    Returns (planes (B, n_out * n_co * 9, H, W), n_co); dkt_head_finish or dkt_motion_front_c8 sums the shifted planes."""
     s0 = srcs[0]
     hw = _head_weights(layer2)
     nout = int(hw.shape[0])
-    L = _ffi.lib()
-    n_co = L.dkt_conv2d_c8_head_blocks(int(layer1.weight.shape[0]), cfg)
+    n_co = _ffi.lib().dkt_conv2d_c8_head_blocks(int(layer1.weight.shape[0]), cfg)
     if n_co <= 0:
         raise _ffi.DktError("conv_c8.head: tile shape %d cannot run the head epilogue" % cfg)
     planes = torch.empty((s0.B, nout * n_co * 9, s0.H, s0.W), device=s0.device, dtype=torch.float32)
     d = desc(srcs, layer1, relu=True, epilogue=3, head_w=hw, head_out=planes)
     launch(d, planes, cfg)
+    return planes, n_co
+
+
+def motion_front_supported(corr, enc):
+    """True when dkt_motion_front_c8 covers this correlation block (skewed four-level pyramid, radius 3 / 4) and motion
+    encoder (1x1 convc1 with <= 64 outputs on the lookup, 7x7 convf1 on a <= 4 channel flow)."""
+    w, wf = enc.convc1.weight, enc.convf1.weight
+    K = 2 * getattr(corr, "radius", 0) + 1
+    return (getattr(corr, "_skew", None) is not None and getattr(corr, "num_levels", 0) == 4 and corr.radius in (3, 4)
+            and (corr._w2 >> 3) >= 2 and tuple(w.shape[2:]) == (1, 1) and w.shape[0] <= 64 and w.shape[1] == 4 * K
+            and tuple(wf.shape[2:]) == (7, 7) and wf.shape[1] <= 4 and tuple(enc.convf1.padding) == (3, 3))
+
+
+def motion_front(corr, planes, n_co, head_bias, x_old, x_new, x0, flow, convc1, cor, convf1, flo):
+    """One launch for the step between the flow head and the motion encoder's 3x3 layers (dkt_motion_front_c8):
+    x_new = x_old + sum of the head's shifted `planes` + head_bias (what dkt_head_finish computes), flow[:, 0] = x_new - x0,
+    cor = C8S(relu(convc1(corr(x_new)))), flo = C8S(relu(convf1(flow))).  x_old, x_new, x0: (B, 1, H, W) views (dense rows)."""
+    from . import conv as _conv
+    from .corr import _kmajor_weight
+    B, _, H, W = x_old.shape
+    for t in (x_old, x_new, x0):
+        if t.shape != x_old.shape or t.stride(3) != 1 or t.stride(2) != W:
+            raise ValueError("motion_front: coordinate planes must be (B, 1, H, W) with dense rows")
+    if flow.shape[0] != B or tuple(flow.shape[2:]) != (H, W) or not flow[0].is_contiguous() or flow.shape[1] != convf1.weight.shape[1]:
+        raise ValueError("motion_front: flow must be (B, Cin of convf1, H, W), dense per batch item")
+    if (cor.B, cor.H, cor.W) != (B, H, W) or (flo.B, flo.H, flo.W) != (B, H, W):
+        raise ValueError("motion_front: C8S destinations of another shape")
+    if x_new.data_ptr() == x_old.data_ptr():
+        raise ValueError("motion_front: x_new must not alias x_old")
+    L = _ffi.lib()
+    wf, bf = convf1.weight, convf1.bias
+    key = (wf.data_ptr(), wf._version, None if bf is None else (bf.data_ptr(), bf._version))
+    with _CACHE_LOCK:
+        pk = _conv._stem7_packed(convf1, key, L)
+    in_scale = 2.0 ** _conv.in_exp_of(convf1)
+    wm = _kmajor_weight(convc1)
+    bc = convc1.bias
+    skew = _ffi.ptr_array(corr._skew)
+    d = _ffi.MotionFrontDesc(
+        skew=skew, planes=planes.data_ptr(), planes_bstride=planes.stride(0), n_co=n_co,
+        head_bias=None if head_bias is None else head_bias.detach().data_ptr(),
+        x_old=x_old.data_ptr(), x_old_bstride=x_old.stride(0), x_new=x_new.data_ptr(), x_new_bstride=x_new.stride(0),
+        x0=x0.data_ptr(), x0_bstride=x0.stride(0), flow=flow.data_ptr(), flow_bstride=flow.stride(0),
+        w_cor=wm.data_ptr(), b_cor=None if bc is None else bc.detach().data_ptr(), cor_channels=int(convc1.weight.shape[0]),
+        cor_c8=cor.data_ptr(), cor_c8_bstride_bytes=cor.bstride_bytes, cor_c8_ch0=0, cor_act_scale=cor.scale,
+        stem_w_hi=pk.hi.data_ptr(), stem_w_lo=pk.lo.data_ptr(), stem_bias=None if pk.bias is None else pk.bias.data_ptr(),
+        stem_out_scale=pk.inv_scale / in_scale, stem_in_scale=in_scale, stem_cin=int(wf.shape[1]), stem_cout=int(wf.shape[0]),
+        flo_c8=flo.data_ptr(), flo_c8_bstride_bytes=flo.bstride_bytes, flo_c8_ch0=0, flo_act_scale=flo.scale,
+        B=B, H=H, W1=W, W2=corr._w2, L=corr.num_levels, r=corr.radius)
+    rc = L.dkt_motion_front_c8(ctypes.byref(d), _ffi.device_of(x_old), _ffi.stream_of(x_old))
+    _ffi.check(rc, "dkt_motion_front_c8")
+
+
+def head(srcs, layer1, layer2, target, diff=None, cfg=2):
+    """target += layer2(relu(layer1(cat(srcs)))) for the flow / disparity head (core/update.py:6-14; raft_stereo.py:165-168),
+    `layer2` a 3x3 layer with 1 or 2 outputs: the hidden tensor is never written -- layer1's epilogue reduces it against
+    layer2's weights tap by tap (epilogue 3), dkt_head_finish adds the shifted planes.  diff = (ref, dst): dst = target - ref."""
+    s0 = srcs[0]
+    L = _ffi.lib()
+    planes, n_co = head_planes(srcs, layer1, layer2, cfg)
+    nout = planes.shape[1] // (n_co * 9)
     b2 = layer2.bias
     ref, dst = diff if diff is not None else (None, None)
     rc = L.dkt_head_finish(planes.data_ptr(), planes.stride(0), n_co, None if b2 is None else b2.detach().data_ptr(),

@@ -224,16 +224,7 @@ class CorrBlock1D:
         if coords.stride(3) != 1 or coords.stride(2) != W1:
             coords = coords.contiguous()
         cout = w.shape[0]
-        # the kernel wants the weight k-major, (L*K, Cout); cached on the layer per device and version
-        # (under the lock: a thread that lost a creation race would otherwise free the tensor another
-        # thread's captured graph already points to)
-        key = (w.data_ptr(), w._version)
-        with _WT_LOCK:
-            cache = layer.__dict__.setdefault("_dkt_wt", {})
-            hit = cache.get(str(w.device))
-            if hit is None or hit[0] != key:
-                hit = cache[str(w.device)] = (key, w.detach().reshape(cout, -1).t().float().contiguous())
-        wm = hit[1]
+        wm = _kmajor_weight(layer)
         bias = layer.bias
         if out_c8 is not None:
             # straight into the C8S operand of the next convolution (conv_c8.hip); four levels only
@@ -267,6 +258,20 @@ class CorrBlock1D:
         else:
             lvl0, = _build_pyramid(fmap1.float(), fmap2.float(), 1, divisor)
         return lvl0.view(B, H, W1, 1, W2)
+
+
+def _kmajor_weight(layer):
+    """The 1x1 layer's weight k-major, (L*K, Cout), as the fused lookup kernels read it; cached on the layer per device and
+    version (under the lock: a thread that lost a creation race would otherwise free the tensor another thread's captured
+    graph already points to)."""
+    w = layer.weight
+    key = (w.data_ptr(), w._version)
+    with _WT_LOCK:
+        cache = layer.__dict__.setdefault("_dkt_wt", {})
+        hit = cache.get(str(w.device))
+        if hit is None or hit[0] != key:
+            hit = cache[str(w.device)] = (key, w.detach().reshape(w.shape[0], -1).t().float().contiguous())
+    return hit[1]
 
 
 class CorrBlockFast1D(CorrBlock1D):

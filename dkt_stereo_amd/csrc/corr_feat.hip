@@ -415,17 +415,19 @@ __global__ __launch_bounds__(256) void corr_feat16_kernel(CorrFeatArgs a) {
 // (Round 4 tried two segments per block, software-pipelined -- segment 1's window loads in flight under segment 0's MFMAs and
 // stores, weights fetched once: 70 us against 62 at B = 8.  Fewer, longer blocks lose more latency hiding than the pipelining
 // inside one block wins; not kept.)
-template <int R>
-__global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
+// bx = row segment index (row-major over (H, ceil(W1 / 64))), b = batch item; coord(b, p, live, g) = the x coordinate of pixel
+// p = hrow * W1 + w1 (called by every lane of every wave g; the plain kernel reads coords_x, the fused motion-encoder front
+// below computes the coordinate update of dkt_head_finish there).
+template <int R, class CX>
+__device__ __forceinline__ void corr_feat64_body(const CorrFeatArgs &a, long bx, int b, CX coord) {
     constexpr int K = 2 * R + 1;
     constexpr int PITCH = 65;          // (80 -- k rows 16 banks apart -- measured the same: LDS is not the limiter)
     __shared__ float vs[4 * K * PITCH];
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nseg = (a.W1 + 63) / 64;
-    const long hrow = blockIdx.x / nseg;
-    const int seg0 = (int)(blockIdx.x - hrow * nseg) * 64;
-    const int b = blockIdx.y;
+    const long hrow = bx / nseg;
+    const int seg0 = (int)(bx - hrow * nseg) * 64;
     // phase 2's weight fragments (wave m = g: channels 16m .. 16m+15, k = 4 step + q) are fetched FIRST: left inside the
     // k loop each of them was an L2 round trip on the critical path behind the barrier (the 36 x 64 matrix is shared by
     // every block, but a block touches it once) -- issued here their latency hides under the sampling phase
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
         const bool live = w1 < a.W1;
         const int w1c = live ? w1 : a.W1 - 1;
         const long p = hrow * a.W1 + w1c;
-        const float cx = a.coords_x[(size_t)b * a.coords_bstride + p];
+        const float cx = coord(b, p, live, g);
         const int lv = g;
         const int wi = a.W2 >> lv;
         const int qm = (w1c >> lv) % wi;
@@ -560,6 +562,80 @@ __global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
 }
 
 template <int R>
+__global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
+    corr_feat64_body<R>(a, (long)blockIdx.x, (int)blockIdx.y,
+                        [&](int b, long p, bool, int) -> float { return a.coords_x[(size_t)b * a.coords_bstride + p]; });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The motion encoder's front as ONE launch (round 4): the coordinate update that closes the flow head
+// (dkt_head_finish: coords1 += conv2(relu(conv1(h))), flow = coords1 - coords0; raft_stereo.py:165-168), the lookup
+// + convc1 at the NEW coordinate (core/corr.py:127-146, core/update.py:76,84) and the 7x7 stem on the NEW flow
+// (core/update.py:77,85) were three dependent launches of 14 + 23 + 39 us on the loop's critical chain.  Here blocks
+// [0, nb_stem) are stem tiles (4 rows x 32 columns + 3 pixels of halo: the update is recomputed for the halo, 18 plane
+// reads per position) and the rest are lookup row segments; both evaluate the update with dkt_head_finish's own
+// operation order, so the lookup, the stem and the stored coordinate see one value per pixel.  The OLD coordinate is
+// read from x_old and the new one written to x_new != x_old (the caller alternates two buffers: a stem tile's halo
+// belongs to another block's segment, which may already have stored its result); the lookup blocks own the stores.
+#include "stem7_body.h"
+
+struct FrontArgs {
+    CorrFeatArgs cf;
+    Stem7Args s7;
+    const float *planes; long planes_bs; int n_co;      // epilogue-3 planes of the head's first layer: [(co block) * 9 + tap][H][W]
+    const float *head_bias;                             // bias of the head's second layer (output 0) or null
+    const float *x_old; long x_old_bs;                  // coords1[:, 0] before the update
+    float *x_new; long x_new_bs;                        // ... after it
+    const float *x0; long x0_bs;                        // coords0[:, 0]
+    float *flow; long flow_bs;                          // flow (B, Cin, H, W): channel 0 written, channels 1.. read by the stem
+    int nb_stem;
+};
+
+// dkt_head_finish (conv_c8.hip) for one output and one pixel: the shifted planes in (co block, tap) order, then the bias
+__device__ __forceinline__ float front_coord(const FrontArgs &f, int b, int oh, int ow, long p) {
+    const int H = f.cf.H, W = f.cf.W1;
+    const long HW = f.cf.HW;
+    float s = 0.0f;
+    for (int cb = 0; cb < f.n_co; ++cb) {
+        const float *pl = f.planes + (long)b * f.planes_bs + (long)cb * 9 * HW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+            const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+            const float v = pl[(long)t * HW + (in ? (long)ih * W + iw : 0)];
+            s = __fadd_rn(s, in ? v : 0.0f);
+        }
+    }
+    s = __fadd_rn(s, f.head_bias ? f.head_bias[0] : 0.0f);
+    return __fadd_rn(f.x_old[(long)b * f.x_old_bs + p], s);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void motion_front_kernel(FrontArgs f) {
+    const int b = blockIdx.y;
+    if ((int)blockIdx.x < f.nb_stem) {
+        const long HW = f.cf.HW;
+        const float *fl = f.flow + (long)b * f.flow_bs;
+        const float *x0 = f.x0 + (long)b * f.x0_bs;
+        stem7_tile(f.s7, (int)(blockIdx.x / f.s7.n_co), (int)(blockIdx.x % f.s7.n_co), b, [&](int ih, int iw, long off, float (&v)[4]) {
+            v[0] = __fsub_rn(front_coord(f, b, ih, iw, off), x0[off]);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) v[c] = fl[(long)(c < f.s7.Cin ? c : 0) * HW + off];
+        });
+        return;
+    }
+    corr_feat64_body<R>(f.cf, (long)blockIdx.x - f.nb_stem, b, [&](int bb, long p, bool live, int g) -> float {
+        const int oh = (int)(p / f.cf.W1), ow = (int)(p - (long)oh * f.cf.W1);
+        const float nx = front_coord(f, bb, oh, ow, p);
+        if (g == 0 && live) {
+            f.x_new[(long)bb * f.x_new_bs + p] = nx;
+            f.flow[(long)bb * f.flow_bs + p] = __fsub_rn(nx, f.x0[(long)bb * f.x0_bs + p]);
+        }
+        return nx;
+    });
+}
+
+template <int R>
 static int cf16_launch(CorrFeatArgs a, int B, hipStream_t st) {
     a.nseg = (a.W1 + 15) / 16;
     const long waves = (long)a.H * a.nseg;
@@ -649,4 +725,68 @@ extern "C" int dkt_corr1d_lookup_conv1x1_c8(const float *const *skew, const floa
     if (!out_c8) return DKT_E_NULL;
     return corr_feat_impl(skew, coords_x, coords_bstride, weight, bias, nullptr, 0, nullptr, 0, out_c8, out_c8_bstride_bytes,
                           out_c8_ch0, act_scale, B, H, W1, W2, L, r, Cout, relu, device, stream);
+}
+
+// ---- the fused front (motion_front_kernel above)
+extern "C" int dkt_motion_front_c8(const dkt_motion_front_desc *d, int device, void *stream) {
+    if (!d) return DKT_E_NULL;
+    if (!d->skew || !d->planes || !d->x_old || !d->x_new || !d->x0 || !d->flow || !d->w_cor || !d->cor_c8 || !d->stem_w_hi ||
+        !d->stem_w_lo || !d->flo_c8)
+        return DKT_E_NULL;
+    if (d->x_new == d->x_old) return DKT_E_SHAPE;          // a stem tile's halo would read another block's result
+    const int B = d->B, H = d->H, W1 = d->W1, W2 = d->W2, L = d->L, r = d->r;
+    if (B <= 0 || H <= 0 || W1 <= 0 || W2 <= 0 || B > 65535 || d->n_co < 1) return DKT_E_SHAPE;
+    if (L != 4 || (r != 4 && r != 3) || d->cor_channels <= 0 || d->cor_channels > 64 || (W2 >> (L - 1)) < 2) return DKT_E_UNSUPPORTED;
+    if (d->stem_cin < 1 || d->stem_cin > 4 || d->stem_cout <= 0) return DKT_E_SHAPE;
+    if ((d->cor_c8_ch0 & 7) || (d->flo_c8_ch0 & 7) || !(d->cor_act_scale > 0.0f) || !(d->flo_act_scale > 0.0f) ||
+        !(d->stem_in_scale > 0.0f) || !(d->stem_out_scale > 0.0f))
+        return DKT_E_SHAPE;
+    FrontArgs f;
+    CorrFeatArgs &a = f.cf;
+    for (int i = 0; i < DKT_MAX_LEVELS; ++i) {
+        a.skew.p[i] = i < L ? d->skew[i] : nullptr;
+        if (i < L && !d->skew[i]) return DKT_E_NULL;
+        const int wi = i < L ? (W2 >> i) : 0;
+        a.inv_wm1[i] = wi > 1 ? (float)(1.0 / (double)(wi - 1)) : 0.0f;
+    }
+    a.coords_x = nullptr; a.coords_bstride = 0;
+    a.w = d->w_cor; a.bias = d->b_cor;
+    a.out = nullptr; a.out_bstride = 0; a.tap = nullptr; a.tap_bstride = 0;
+    a.HW = (long)H * W1;
+    a.H = H; a.W1 = W1; a.W2 = W2;
+    a.pitch = (W1 + 31) & ~31;
+    a.nseg = (W1 + 31) / 32;
+    a.Cout = d->cor_channels;
+    a.relu = 1;
+    int Hp = 0, Wp = 0;
+    dkt_act_c8_dims(H, W1, &Hp, &Wp);
+    a.out_c8 = (char *)d->cor_c8; a.out_c8_bs = d->cor_c8_bstride_bytes; a.out_c8_plane = (long)Hp * Wp * 16;
+    a.out_c8_Wp = Wp; a.out_c8_ch0 = d->cor_c8_ch0; a.act_scale = d->cor_act_scale;
+    Stem7Args &s = f.s7;
+    s.x = nullptr; s.x_bs = 0;
+    s.whi = (const _Float16 *)d->stem_w_hi; s.wlo = (const _Float16 *)d->stem_w_lo;
+    s.bias = d->stem_bias; s.out_scale = d->stem_out_scale; s.in_scale = d->stem_in_scale;
+    s.y = nullptr; s.y_bs = 0;
+    s.Cin = d->stem_cin; s.Cout = d->stem_cout; s.CoutPad = (d->stem_cout + 63) & ~63;
+    s.H = H; s.W = W1;
+    s.tiles_w = (W1 + 31) / 32;
+    s.tiles_xy = s.tiles_w * ((H + 3) / 4);
+    s.n_co = s.CoutPad / 64;
+    s.relu = 1;
+    s.y_c8 = (char *)d->flo_c8; s.y_c8_bs = d->flo_c8_bstride_bytes; s.y_c8_plane = (long)Hp * Wp * 16; s.y_c8_Wp = Wp;
+    s.y_c8_ch0 = d->flo_c8_ch0; s.act_scale = d->flo_act_scale;
+    f.planes = d->planes; f.planes_bs = d->planes_bstride; f.n_co = d->n_co;
+    f.head_bias = d->head_bias;
+    f.x_old = d->x_old; f.x_old_bs = d->x_old_bstride;
+    f.x_new = d->x_new; f.x_new_bs = d->x_new_bstride;
+    f.x0 = d->x0; f.x0_bs = d->x0_bstride;
+    f.flow = d->flow; f.flow_bs = d->flow_bstride;
+    const long nb_stem = (long)s.tiles_xy * s.n_co, nb_look = (long)H * ((W1 + 63) / 64);
+    if (nb_stem + nb_look > 0x7fffffffL) return DKT_E_SHAPE;
+    f.nb_stem = (int)nb_stem;
+    DKT_ENTER(device);
+    dim3 grid((unsigned)(nb_stem + nb_look), (unsigned)B);
+    if (r == 4) hipLaunchKernelGGL(motion_front_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, f);
+    else hipLaunchKernelGGL(motion_front_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, f);
+    return dkt_launch_status();
 }

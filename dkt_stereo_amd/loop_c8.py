@@ -39,6 +39,9 @@ RANGE_LO, RANGE_HI = 6, 14
 #: the middle GRU's chain of the next iteration on a second stream beside the head and the motion encoder (DKT_C8_FORK=0: one stream)
 #: (=2: also the motion encoder's 7x7 stem beside the lookup on a third stream -- measured 0.25 ms per pair SLOWER, kept for A/B)
 FORK = int(os.environ.get("DKT_C8_FORK", "1"))
+#: the coordinate update behind the flow head, the lookup + convc1 and the motion encoder's 7x7 stem as ONE launch
+#: (dkt_motion_front_c8; the x coordinate alternates between two buffers, see C8Loop.unit)
+FRONT = True
 #: the two resampling jobs in front of / behind the middle GRU as one launch each (dkt_resample_pair_c8)
 PAIR_RESAMPLE = True
 #: the flow head is the fused GRU launch's first successor in the captured unit (see C8Loop.unit)
@@ -73,7 +76,12 @@ def _eligible_block(ub, shape, enc_out):
     if any(getattr(m, "dkt_in_exp", 0) for m in ub.modules()):
         return False                      # calibrated activation exponents: the round-2 kernels handle those
     hd = list(a.hidden_dims)
-    return hd == [128, 128, 128] and ub.encoder.conv.weight.shape[0] == enc_out
+    enc = ub.encoder
+    stem = getattr(enc, "convf1", None) or getattr(enc, "convd1", None)
+    # (the loop's C8S buffers are laid out for the reference's layer widths: 64 + 64 -> 128 motion features)
+    return (hd == [128, 128, 128] and enc.conv.weight.shape[0] == enc_out and enc.convc1.weight.shape[0] == 64
+            and stem is not None and stem.weight.shape[0] == 64 and tuple(stem.weight.shape[2:]) == (7, 7)
+            and enc.convc2.weight.shape[:2] == (64, 64))
 
 
 class C8Loop:
@@ -99,42 +107,54 @@ class C8Loop:
         self.gflags = [c8.gru_flags(B, n.shape[2], n.shape[3], dev) for n in (n0, n1, n2)]
         self.err = torch.zeros(1, device=dev, dtype=torch.int32)
         self.fuse_gru = FUSE_GRU
-        self.graph = None                # one captured unit
-        self.graph_n = None              # GRAPH_UNITS captured units
-        self.graph_last = None           # the final unit of a pair
+        # captured units, per parity of the coordinate buffer they start from (self.par; always 0 without the fused front)
+        self.graph = None                # [parity] one unit
+        self.graph_n = None              # [parity] GRAPH_UNITS units
+        self.graph_last = None           # [parity] the final unit of a pair
+        self.front = bool(FRONT) and self._front_supported(st)
+        self.par = 0                     # which of self.cx holds the current x coordinate
+        self.cx = None
         self.calibrated = not AUTOSCALE
 
     # ---- captured units -------------------------------------------------------------------------------------------
+    def _front_supported(self, st):
+        from . import conv_c8
+        return "corr" in st and conv_c8.motion_front_supported(st["corr"], self.ub.encoder)
+
     def capture(self, st, capture_graph):
-        """Captures one unit, and GRAPH_UNITS units back to back (capturing records, it does not execute)."""
+        """Captures one unit, the final unit, and GRAPH_UNITS units back to back (capturing records, it does not execute) --
+        with the fused front once per parity of the coordinate buffer the sequence starts from."""
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with capture_graph(g):
-            self.unit(st)
-        self.graph = g
-        gl = torch.cuda.CUDAGraph()
-        with capture_graph(gl):
-            self.unit(st, last=True)
-        self.graph_last = gl
-        self.graph_n = None
-        if GRAPH_UNITS > 1:
-            gn = torch.cuda.CUDAGraph()
-            with capture_graph(gn):
-                for _ in range(GRAPH_UNITS):
-                    self.unit(st)
-            self.graph_n = gn
+        keep = self.par
+        self.graph, self.graph_last, self.graph_n = {}, {}, {}
+        for p in ((0, 1) if self.front else (0,)):
+            def cap(fn):
+                self.par = p
+                g = torch.cuda.CUDAGraph()
+                with capture_graph(g):
+                    fn()
+                return g
+            self.graph[p] = cap(lambda: self.unit(st))
+            self.graph_last[p] = cap(lambda: self.unit(st, last=True))
+            if GRAPH_UNITS > 1:
+                self.graph_n[p] = cap(lambda: [self.unit(st) for _ in range(GRAPH_UNITS)])
+        self.par = keep
 
     def replay(self, n, last=False):
         """n units from the captured graphs (`last`: the n-th is the pair's final one)."""
         if last:
             n -= 1
-        while self.graph_n is not None and n >= GRAPH_UNITS:
-            self.graph_n.replay()
-            n -= GRAPH_UNITS
+        step = GRAPH_UNITS if GRAPH_UNITS % 2 == 0 or not self.front else 0      # (an odd run of units would end on the other parity)
+        while self.graph_n and step and n >= step:
+            self.graph_n[self.par].replay()
+            n -= step
         for _ in range(n):
-            self.graph.replay()
+            self.graph[self.par].replay()
+            if self.front:
+                self.par ^= 1
         if last:
-            self.graph_last.replay()
+            self.graph_last[self.par].replay()
+            self.par = 0                 # (the final unit leaves the coordinate in st["coords1"])
 
     _tail_channels = 2                   # flow (x, y) behind the 126 motion features (core/update.py:85)
 
@@ -198,6 +218,7 @@ class C8Loop:
                 break
         self.calibrated = True
         self.graph = self.graph_n = self.graph_last = None     # (a captured unit bakes the scales in)
+        self.par = 0
 
     def ranges_ok(self):
         """False when a tensor's maximum has left [2^RANGE_LO, 2^RANGE_HI) under its scale (another kind of input than the one
@@ -264,27 +285,59 @@ class C8Loop:
             fn()
         return lambda: main.wait_stream(side)
 
-    def _motion(self, st):
+    def _motion_front(self, st):
+        """convf1 on the flow and the lookup + convc1 (core/update.py:76-77): two launches behind the head's own finish."""
         enc = self.ub.encoder
         join = self._fork_stem(st["flow"], lambda: c8.stem7_c8(st["flow"], enc.convf1, self.flo))
         if st["corr"].lookup_conv1x1(st["coords1"], enc.convc1, out_c8=self.cor) is None:
-            c8.pack(st["corr"].lookup_conv1x1(st["coords1"], enc.convc1), self.cor)
+            cor = st["corr"].lookup_conv1x1(st["coords1"], enc.convc1)
+            if cor is None:       # (row-layout pyramid, other level counts / radii: the lookup tensor, then the 1x1 layer)
+                cor = _conv.conv2d(st["corr"](st["coords1"]), enc.convc1, relu=True)
+            c8.pack(cor, self.cor)
         join()
+
+    def _motion_tail(self, st):
+        enc = self.ub.encoder
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convf2, relu=True, out_c8=self.cf, out_c8_ch0=64)
         c8.launch_pair(d0, d1, st["flow"], _CFG["c2"])
         c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["flow"], cfg=_CFG["enc"])
 
-    def _head(self, st):
+    def _motion(self, st):
+        self._motion_front(st)
+        self._motion_tail(st)
+
+    def _coords(self, st):
+        """The two x-coordinate buffers of the fused front: st["coords1"][:, :1] and a twin."""
+        if self.cx is None or self.cx[0].data_ptr() != st["coords1"].data_ptr():
+            self.cx = [st["coords1"][:, :1], torch.empty_like(st["coords1"][:, :1].contiguous())]
+        return self.cx
+
+    def _head(self, st, front=False):
+        """Flow head (core/update.py:6-14) and the coordinate update (raft_stereo.py:165-168).  `front`: the update, the
+        lookup + convc1 and convf1 of the NEXT iteration's motion encoder in the head's second launch (dkt_motion_front_c8):
+        reads the coordinate from cx[par], writes cx[1 - par]."""
         fh = self.ub.flow_head
+        if front:
+            cx = self._coords(st)
+            planes, n_co = c8.head_planes([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), cfg=_CFG["head"])
+            enc = self.ub.encoder
+            c8.motion_front(st["corr"], planes, n_co, _leading_outputs(fh.conv2, 1).bias, cx[self.par], cx[1 - self.par],
+                            st["coords0"][:, :1], st["flow"], enc.convc1, self.cor, enc.convf1, self.flo)
+            self.par ^= 1
+            return
+        target = self._coords(st)[self.par] if self.front else st["coords1"][:, :1]
         if FUSE_HEAD:
             # conv2 (x output only: raft_stereo.py:165) from per-tap projections made in conv1's epilogue
-            c8.head([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), st["coords1"][:, :1],
+            c8.head([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), target,
                     diff=(st["coords0"][:, :1], st["flow"][:, :1]), cfg=_CFG["head"])
-            return
-        c8.conv2d_c8([self.hc8[0]], fh.conv1, relu=True, out=self.hidden, cfg=_CFG["head"])
-        _conv.conv2d_accumulate(self.hidden, _leading_outputs(fh.conv2, 1), st["coords1"][:, :1],
-                                diff=(st["coords0"][:, :1], st["flow"][:, :1]))
+        else:
+            c8.conv2d_c8([self.hc8[0]], fh.conv1, relu=True, out=self.hidden, cfg=_CFG["head"])
+            _conv.conv2d_accumulate(self.hidden, _leading_outputs(fh.conv2, 1), target,
+                                    diff=(st["coords0"][:, :1], st["flow"][:, :1]))
+        if self.front and self.par:
+            self.cx[0].copy_(self.cx[1])          # the pair's final coordinate lives in st["coords1"]
+            self.par = 0
 
     def _mid(self, st):
         n0, n1, n2 = st["net"]
@@ -309,6 +362,7 @@ class C8Loop:
         if last:
             self._head(st)
             return
+        front = self.front and FUSE_HEAD
         if FORK:
             from .update import _side_stream
             dev = st["net"][0].device
@@ -320,24 +374,29 @@ class C8Loop:
                 # boundary (a cross-queue dependency costs ~10 us of idle device, twice per iteration)
                 forked = torch.cuda.Event()
                 forked.record(main)
-                self._head(st)
+                self._head(st, front)
                 side.wait_event(forked)
             else:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._mid(st)
             if not HEAD_FIRST:
-                self._head(st)
-            self._motion(st)
+                self._head(st, front)
+            if not front:
+                self._motion_front(st)
+            self._motion_tail(st)
             main.wait_stream(side)
         else:
-            self._head(st)
+            self._head(st, front)
             self._mid(st)
-            self._motion(st)
+            if not front:
+                self._motion_front(st)
+            self._motion_tail(st)
 
     def prologue(self, st):
         """Per pair: hidden states into their C8S twins, the coarsest and the middle GRU of iteration 0 and its motion features."""
         n0, n1, n2 = st["net"]
+        self.par = 0
         for lvl, n in enumerate(st["net"]):
             c8.pack(n, self.hc8[lvl])
         c8.pool2x_c8(n1, self.pool1)
@@ -355,6 +414,9 @@ class C8LoopIGEV(C8Loop):
 
     _tail_channels = 1                   # the running disparity behind the 127 motion features (igev_stereo/update.py:92)
 
+    def _front_supported(self, st):
+        return False                     # (the geometry lookup has its own fused kernel, geo_feat.hip)
+
     @staticmethod
     def _gru_modules(ub):
         return ub.gru04, ub.gru08, ub.gru16
@@ -362,7 +424,7 @@ class C8LoopIGEV(C8Loop):
     def _state(self, st):
         return [*st["net"], st["disp"]]
 
-    def _motion(self, st):
+    def _motion_front(self, st):
         enc = self.ub.encoder
         # geometry lookup + convc1 + ReLU in one kernel, straight into the C8S operand (dkt_geo_lookup_conv1x1)
         join = self._fork_stem(st["disp"], lambda: c8.stem7_c8(st["disp"], enc.convd1, self.flo))
@@ -370,11 +432,14 @@ class C8LoopIGEV(C8Loop):
             geo = st["geo_fn"](st["disp"], st["coords"])
             c8.pack(_conv.conv2d(geo, enc.convc1, relu=True), self.cor)
         join()
+
+    def _motion_tail(self, st):
+        enc = self.ub.encoder
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convd2, relu=True, out_c8=self.cf, out_c8_ch0=64)
         c8.launch_pair(d0, d1, st["disp"], _CFG["c2"])
         c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["disp"], cfg=_CFG["enc"])
 
-    def _head(self, st):
+    def _head(self, st, front=False):
         dh = self.ub.disp_head
         c8.head([self.hc8[0]], dh.conv1, dh.conv2, st["disp"], cfg=_CFG["head"])      # disp += delta (igev_stereo.py:209)

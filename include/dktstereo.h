@@ -518,6 +518,27 @@ int dkt_pool2x_c8(const float *x, long x_bstride, void *dst, long dst_bstride_by
                   int ch0, float scale, int device, void *stream);
 int dkt_interp_c8(const float *x, long x_bstride, void *dst, long dst_bstride_bytes, int B, int C, int H, int W,
                   int Ho, int Wo, int ch0, float scale, int device, void *stream);
+/* The motion encoder's front as one launch (round 4): the coordinate update that closes the flow head (what dkt_head_finish
+ * does: coords1[:, 0] += conv2(relu(conv1(h)))[:, 0], flow[:, 0] = coords1[:, 0] - coords0[:, 0]; raft_stereo.py:165-168),
+ * dkt_corr1d_lookup_conv1x1_c8 at the NEW coordinate (core/corr.py:127-146 + core/update.py:76,84) and dkt_conv2d_stem7_c8 on
+ * the NEW flow (core/update.py:77,85).  x_new must be another buffer than x_old (the caller alternates two).  Same arithmetic,
+ * bit for bit, as the three launches.  L = 4, r = 3 or 4, cor_channels <= 64. */
+typedef struct dkt_motion_front_desc {
+    const float *const *skew;                   /* dkt_corr1d_skew pyramids (L pointers) */
+    const float *planes; long planes_bstride; int n_co;   /* epilogue-3 planes of the head's first layer, (B, n_co*9, H, W1) */
+    const float *head_bias;                     /* bias of the head's second layer (first output) or null */
+    const float *x_old; long x_old_bstride;     /* coords1[:, 0] in */
+    float *x_new; long x_new_bstride;           /* coords1[:, 0] out */
+    const float *x0; long x0_bstride;           /* coords0[:, 0] */
+    float *flow; long flow_bstride;             /* (B, stem_cin, H, W1): channel 0 written, the others read */
+    const float *w_cor, *b_cor; int cor_channels;   /* convc1: weight k-major (L*K, cor_channels), bias or null */
+    void *cor_c8; long cor_c8_bstride_bytes; int cor_c8_ch0; float cor_act_scale;
+    const void *stem_w_hi, *stem_w_lo; const float *stem_bias;   /* dkt_conv2d_stem7_pack images of convf1 */
+    float stem_out_scale, stem_in_scale; int stem_cin, stem_cout;
+    void *flo_c8; long flo_c8_bstride_bytes; int flo_c8_ch0; float flo_act_scale;
+    int B, H, W1, W2, L, r;
+} dkt_motion_front_desc;
+int dkt_motion_front_c8(const dkt_motion_front_desc *d, int device, void *stream);
 /* two of the resampling jobs above in one launch (round 4: the loop's pool2x(net[0]) | interp(net[2]) in front of the
  * middle ConvGRU and interp(net[1]) | pool2x(net[1]) behind it, core/update.py:120-132); kind 0 = pool2x (Ho, Wo ignored),
  * kind 1 = interp to (Ho, Wo).  Same arithmetic as the single launches. */

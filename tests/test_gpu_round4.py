@@ -281,3 +281,51 @@ def test_resample_pair_equals_single_launches(B, H, W):
             assert torch.equal(p0.t, p1.t) and torch.equal(u0.t, u1.t)
     with pytest.raises(ValueError):
         c8.resample_pair_c8(("pool", fine, c8.ActC8(B, 128, Hm + 1, Wm, DEV)), ("interp", coarse, u0))
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("B,H,W,radius", [(1, 46, 78, 4), (2, 40, 96, 4), (1, 33, 130, 3)])
+def test_motion_front_equals_the_three_launches(B, H, W, radius):
+    """dkt_motion_front_c8 == dkt_head_finish, then lookup + convc1 -> C8S, then the 7x7 stem -> C8S, bit for bit
+    (raft_stereo.py:165-168, core/corr.py:127-146 + core/update.py:76-77): coordinate, flow, both C8S operands; ragged
+    widths (the stem's 32-column and the lookup's 64-pixel tiles both end inside the row), batch strides of a 2-channel
+    coordinate tensor, scaled destinations; x_new aliasing x_old is refused."""
+    from dkt_stereo_amd.corr import CorrBlock1D
+    from dkt_stereo_amd.update import FlowHead, _leading_outputs
+    c8 = _c8()
+    torch.manual_seed(B * 1000 + W)
+    K = 2 * radius + 1
+    fh = FlowHead(128, 256, 2).to(DEV)
+    h = c8.pack(torch.tanh(torch.randn(B, 128, H, W, device=DEV)))
+    f1, f2 = torch.randn(B, 64, H, W, device=DEV), torch.randn(B, 64, H, W, device=DEV)
+    blk = CorrBlock1D(f1, f2, num_levels=4, radius=radius)
+    convc1 = torch.nn.Conv2d(4 * K, 64, 1).to(DEV)
+    convf1 = torch.nn.Conv2d(2, 64, 7, padding=3).to(DEV)
+    xs = torch.arange(W, device=DEV, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+    ys = torch.arange(H, device=DEV, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
+    coords0 = torch.cat([xs, ys], 1).contiguous()
+    start = coords0.clone()
+    start[:, :1] -= 20 * torch.rand(B, 1, H, W, device=DEV)
+    last = _leading_outputs(fh.conv2, 1)
+    planes, n_co = c8.head_planes([h], fh.conv1, last, cfg=2)
+
+    for scale in (1.0, 32.0):
+        # the three launches
+        c_ref, f_ref = start.clone(), torch.zeros(B, 2, H, W, device=DEV)
+        f_ref[:, 1] = 0.25                                   # (the y plane is only read)
+        c8.head([h], fh.conv1, last, c_ref[:, :1], diff=(coords0[:, :1], f_ref[:, :1]), cfg=2)
+        cor_ref, flo_ref = c8.ActC8(B, 64, H, W, DEV, scale=scale), c8.ActC8(B, 64, H, W, DEV, scale=scale)
+        assert blk.lookup_conv1x1(c_ref, convc1, out_c8=cor_ref) is not None
+        c8.stem7_c8(f_ref, convf1, flo_ref)
+        # one launch
+        c_old, c_new, flow = start.clone(), torch.full_like(start, -7.0), torch.zeros(B, 2, H, W, device=DEV)
+        flow[:, 1] = 0.25
+        cor, flo = c8.ActC8(B, 64, H, W, DEV, scale=scale), c8.ActC8(B, 64, H, W, DEV, scale=scale)
+        assert c8.motion_front_supported(blk, type("E", (), dict(convc1=convc1, convf1=convf1)))
+        c8.motion_front(blk, planes, n_co, last.bias, c_old[:, :1], c_new[:, :1], coords0[:, :1], flow, convc1, cor, convf1, flo)
+        assert torch.equal(c_old, start)                                       # the old coordinate is only read
+        assert torch.equal(c_new[:, :1], c_ref[:, :1]) and bool((c_new[:, 1] == -7.0).all())
+        assert torch.equal(flow, f_ref)
+        assert torch.equal(cor.t, cor_ref.t) and torch.equal(flo.t, flo_ref.t)
+    with pytest.raises(ValueError):
+        c8.motion_front(blk, planes, n_co, last.bias, c_old[:, :1], c_old[:, :1], coords0[:, :1], flow, convc1, cor, convf1, flo)

@@ -1,5 +1,6 @@
-"""bench.py with other tile shapes for the loop's layer classes (loop_c8._CFG), e.g.
-    python tools/bench_cfg.py zr16=3,q16=3 --skip-cpu-baseline --steps 15"""
+"""bench.py with other settings of the loop (loop_c8): lower-case keys are tile shapes of loop_c8._CFG, upper-case keys module
+attributes, e.g.
+    python tools/bench_cfg.py zr16=3,q16=3,HEAD_FIRST=0 --skip-cpu-baseline --steps 15"""
 import os
 import runpy
 import sys
@@ -9,7 +10,14 @@ sys.path.insert(0, ROOT)
 import dkt_stereo_amd.loop_c8 as lp  # noqa: E402
 
 if len(sys.argv) > 1 and "=" in sys.argv[1]:
-    lp._CFG.update({k: int(v) for k, v in (kv.split("=") for kv in sys.argv[1].split(","))})
+    for k, v in (kv.split("=") for kv in sys.argv[1].split(",")):
+        if k.startswith("model."):
+            import dkt_stereo_amd.raft_stereo as rs
+            setattr(rs.RAFTStereo, k[6:], int(v))
+        elif k.isupper():
+            setattr(lp, k, type(getattr(lp, k))(int(v)))
+        else:
+            lp._CFG[k] = int(v)
     sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[2:]
 else:
     sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]

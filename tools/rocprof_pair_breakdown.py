@@ -27,7 +27,7 @@ def main():
     lo, hi = idx[a.pair], idx[a.pair + 1]
     win = rows[lo:hi]
     if a.timeline is not None:
-        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"]]
+        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"] or "motion_front" in r["Kernel_Name"]]
         it = win[lk[a.timeline]:lk[a.timeline + 1]]
         t0 = int(it[0]["Start_Timestamp"])
         print("# dispatches of GRU iteration %d (start offset us, duration us, end offset us, queue, kernel, grid threads); two streams overlap" % a.timeline)
@@ -39,7 +39,7 @@ def main():
                                              r.get("Grid_Size_X", r.get("Grid_Size", ""))))
         print("# iteration wall: %.1f us" % ((int(it[-1]["End_Timestamp"]) - t0) / 1e3))
     if a.phases:
-        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"]]
+        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"] or "motion_front" in r["Kernel_Name"]]
         end = lk[-1] + (lk[-1] - lk[-2])          # the last iteration is as long as the one before it
         table(win[:end], a.top, "GRU loop (corr build + %d iterations)" % len(lk))
         table(win[end:], a.top, "upsampling + encoders")
