@@ -69,6 +69,9 @@ _ENCODER_STATES = weakref.WeakKeyDictionary()      # same, for the captured enco
 _GRAPH_LOCK = threading.Lock()
 
 
+_HANDOVER = threading.local()
+
+
 class RAFTStereo(nn.Module):
     @property
     def _graph_state(self):
@@ -130,8 +133,9 @@ class RAFTStereo(nn.Module):
 
     # -- pieces of the reference forward, split so the hot path can be timed alone --
     def encode(self, image1, image2):
-        """raft_stereo.py:91-116: normalisation, encoders, context split.  With the captured graph the returned
-        tensors are the graph's static outputs: valid until the next encode() on this thread."""
+        """raft_stereo.py:91-116: normalisation, encoders, context split.  The returned hidden states and context terms are
+        valid until the next encode() or iterate() on this thread: once the captured loop exists for this shape they ARE
+        its state buffers (adopt_encoder_outputs; with graph_encoders the captured pass's static outputs)."""
         if (self.use_hip_graph and self.graph_encoders and not getattr(self, "_is_replica", False) and image1.is_cuda and image1.dtype == torch.float32
                 and image2.dtype == torch.float32 and image1.shape == image2.shape
                 and not torch.is_grad_enabled() and not _conv.calibrating()):
@@ -139,7 +143,9 @@ class RAFTStereo(nn.Module):
         return self._encode(image1, image2)
 
     def _encode_graphed(self, image1, image2):
-        key = (image1.device, tuple(image1.shape), self.args.n_gru_layers, self._encoder_fingerprint())
+        target = self._prebuild_target(image1)
+        key = (image1.device, tuple(image1.shape), self.args.n_gru_layers, self._encoder_fingerprint(),
+               None if target is None else (id(target), tuple(p.data_ptr() for p in target.corr_pyramid)))
         tid = threading.get_ident()
         with _GRAPH_LOCK:
             st = _ENCODER_STATES.setdefault(self, {}).get(tid)
@@ -151,13 +157,54 @@ class RAFTStereo(nn.Module):
             with capture_graph(g):
                 st["out"] = self._encode(st["img1"], st["img2"])
             st["graph"] = g
+            st["prebuilt"] = self._prebuilt          # the correlation block the captured pass rebuilds (or None)
             with _GRAPH_LOCK:
                 _ENCODER_STATES.setdefault(self, {})[tid] = st
+            self._static_ctx = None                  # (this call's tensors are the eager pass's, not the graph's)
             return out
         st["img1"].copy_(image1)
         st["img2"].copy_(image2)
         replay_graph(st["graph"])
+        self._prebuilt = st["prebuilt"]
+        self._static_ctx = st["out"]                 # the graph's static outputs: iterate() may adopt them as its state buffers
         return st["out"]
+
+    #: the all-pairs volume + pyramid + skewed copy of the pair are built at the end of the feature encoder's stream, inside
+    #: the captured encoder pass and beside the context encoder's tail of small launches, instead of behind both encoders
+    prebuild_corr = True
+    #: the refinement loop works in the captured encoder pass's own output tensors (hidden states, context terms) instead of
+    #: copying them into buffers of its own (13 device copies per pair)
+    adopt_encoder_outputs = True
+    # hand-over from encode() to iterate() on the same thread (per thread, like the captured states themselves)
+    def _handover(name):
+        def get(self):
+            return getattr(_HANDOVER, "d", {}).get((id(self), name))
+
+        def put(self, value):
+            d = _HANDOVER.__dict__.setdefault("d", {})
+            if value is None:
+                d.pop((id(self), name), None)
+            else:
+                d[(id(self), name)] = value
+        return property(get, put)
+
+    _prebuilt = _handover("prebuilt")        # the correlation block encode() has rebuilt for the pair at hand
+    _static_ctx = _handover("static")        # encode()'s outputs when they are the captured pass's static tensors
+    del _handover
+
+    def _prebuild_target(self, image1):
+        """The persistent correlation block of the captured loop, when this pair's volume can be rebuilt into it."""
+        st = self._graph_state
+        if not (self.prebuild_corr and self.use_hip_graph and st is not None and image1.is_cuda):
+            return None
+        corr = st.get("corr")
+        f = st.get("fmap_shape")
+        n = 2 ** self.args.n_downsample
+        if corr is None or f is None or type(corr).__name__ != "CorrBlock1D":
+            return None
+        if (f[0], f[2] * n, f[3] * n) != (image1.shape[0], image1.shape[2], image1.shape[3]):
+            return None
+        return corr
 
     @staticmethod
     def _normalized_pair(image1, image2):
@@ -196,31 +243,69 @@ class RAFTStereo(nn.Module):
                 side.wait_event(forked)
                 with torch.cuda.stream(side):
                     fmap1, fmap2 = split(self.fnet(fnet_in))
+                    self._prebuild(image1, fmap1, fmap2)
             elif self.encoder_order == 2:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
                 fmap1, fmap2 = split(self.fnet(fnet_in))
+                self._prebuild(image1, fmap1, fmap2)
             else:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     fmap1, fmap2 = split(self.fnet(fnet_in))
+                    self._prebuild(image1, fmap1, fmap2)
                 cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
             main.wait_stream(side)
         else:
+            self._prebuilt = None
             cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
             fmap1, fmap2 = split(self.fnet(fnet_in))
         net_list = [x[0] for x in cnet_list]
         inp_list = [x[1] for x in cnet_list]
         return fmap1.float(), fmap2.float(), net_list, inp_list
 
+    def _prebuild(self, image1, fmap1, fmap2):
+        """core/corr.py:148-156 + :111-125 for this pair into the captured loop's correlation block, on the feature
+        encoder's stream (see prebuild_corr); iterate() finds it done."""
+        self._prebuilt = None
+        corr = self._prebuild_target(image1)
+        if corr is not None and tuple(fmap1.shape) == tuple(self._graph_state["fmap_shape"]):
+            corr.rebuild(fmap1.float(), fmap2.float())
+            self._prebuilt = corr
+
     def _context_post(self, i, outs):
         """raft_stereo.py:103-106 for scale i: tanh of the hidden head, relu + context_zqr convolution of the context
         head (split into the cz, cr, cq operands of that scale's GRU) -- run by the context encoder on the stream of
         the scale's heads."""
         conv = self.context_zqr_convs[i]
+        tgt = self._context_targets(i, outs)
+        if tgt is not None:
+            # straight into the captured loop's state buffers (hidden state; the three context terms as views of one
+            # buffer): iterate() finds them in place and skips its 12 device copies per pair
+            net, ctx = tgt
+            torch.tanh(outs[0], out=net)
+            conv2d(torch.relu(outs[1]), conv, out=ctx)
+            return [net, list(ctx.split(split_size=conv.out_channels // 3, dim=1))]
         return [torch.tanh(outs[0]),
                 list(conv2d(torch.relu(outs[1]), conv).split(split_size=conv.out_channels // 3, dim=1))]
+
+    def _context_targets(self, i, outs):
+        """(hidden-state buffer, context buffer) of scale i in the captured loop's state, when this pass may write them
+        (same thread's state, same shapes, inference on the device)."""
+        st = self._graph_state
+        if not (self.adopt_encoder_outputs and self.use_hip_graph and st is not None and outs[0].is_cuda
+                and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
+            return None
+        ctx = st.get("ctx")
+        if ctx is None or i >= len(ctx):
+            return None
+        net, buf = st["net"][i], ctx[i]
+        conv = self.context_zqr_convs[i]
+        if (net.shape != outs[0].shape or net.device != outs[0].device or buf.shape[1] != conv.out_channels
+                or buf.shape[0] != outs[1].shape[0] or buf.shape[2:] != outs[1].shape[2:] or outs[0].dtype != torch.float32):
+            return None
+        return net, buf
 
     def upsample_flow(self, flow, mask):
         """raft_stereo.py:70-82, convex combination over a 3x3 neighbourhood: one fused kernel
@@ -503,23 +588,41 @@ class RAFTStereo(nn.Module):
         key = (fmap1.device, tuple(fmap1.shape), tuple(fmap2.shape), args.corr_implementation,
                self._weights_fingerprint(), self.rotate, self.pair_grus, self.pipeline_grus, self.fuse_lookup, self.use_c8)
         st = self._graph_state
+        prebuilt, self._prebuilt = self._prebuilt, None
+        static, self._static_ctx = self._static_ctx, None
         if st is None or st["key"] != key:
-            st = dict(key=key, graph=None)
+            st = dict(key=key, graph=None, bound=None, fmap_shape=tuple(fmap1.shape))
             st["corr"] = CORR_IMPLEMENTATIONS[args.corr_implementation](
                 fmap1, fmap2, radius=args.corr_radius, num_levels=args.corr_levels)
             st["coords0"] = coords_grid(b, h, w).to(fmap1.device)
             st["coords1"] = st["coords0"].clone()
             st["net"] = [t.clone() for t in net_list]
-            st["inp"] = [[t.clone() for t in scale] for scale in inp_list]
+            # the three context terms of a scale are views of ONE buffer, the layout the context convolution writes:
+            # the encoder pass of the following pairs writes them (and the hidden states) here itself (_context_targets)
+            st["ctx"] = [torch.cat(list(scale), dim=1) for scale in inp_list]
+            st["inp"] = [list(c.split(split_size=c.shape[1] // 3, dim=1)) for c in st["ctx"]]
             self._graph_state = st
         else:
-            st["corr"].rebuild(fmap1, fmap2)
+            if prebuilt is not st["corr"]:               # (else: the captured encoder pass has rebuilt it for this pair)
+                st["corr"].rebuild(fmap1, fmap2)
             st["coords1"].copy_(st["coords0"])
+            if (self.adopt_encoder_outputs and static is not None and static[2] is net_list and static[3] is inp_list):
+                ptrs = tuple(t.data_ptr() for t in net_list) + tuple(t.data_ptr() for sc in inp_list for t in sc)
+                if st["bound"] != ptrs:
+                    # the captured encoder pass's static outputs become the loop's state buffers: the loop updates the
+                    # hidden states where the encoder writes them (every pair's encoder replay refreshes them) and reads
+                    # the context terms in place; the captured units bake pointers in, so they are captured again
+                    st["net"], st["inp"], st["bound"] = list(net_list), [list(sc) for sc in inp_list], ptrs
+                    st["graph"] = None
+                    if st.get("c8") is not None:
+                        st["c8"].graph = st["c8"].graph_n = st["c8"].graph_last = None
             for dst, src in zip(st["net"], net_list):
-                dst.copy_(src)
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
             for ds, ss in zip(st["inp"], inp_list):
                 for dst, src in zip(ds, ss):
-                    dst.copy_(src)
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src)
         if flow_init is not None:
             st["coords1"].add_(flow_init)
         if self.use_c8 and iters >= 3:
@@ -661,6 +764,11 @@ class RAFTStereo(nn.Module):
             if lp is not None and lp.calibrated and (not finite or not lp.ranges_ok()):
                 # this pair's activations left the window the C8S scales were picked for: pick again, repeat the forward
                 lp.calibrated = False
+                gs = self._graph_state
+                if gs is not None and net_list[0].data_ptr() == gs["net"][0].data_ptr():
+                    # (the encoder pass wrote the hidden states into the loop's own buffers, where the loop has updated
+                    # them in place: produce them again)
+                    fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
                 flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
                 finite = bool(torch.isfinite(flow_up).all())
         if not finite:
