@@ -500,6 +500,26 @@ def conv2d_pair(a, b):
     return res
 
 
+def conv2d_fused_pair(a, b):
+    """conv2d_fused (residual epilogue) for two independent layers in one launch.  a, b = (x, layer, relu, residual);
+    the layers must satisfy ``pair_eligible`` and ``fused_eligible``.  Returns (y_a, y_b)."""
+    res, descs, passes = [], [], None
+    for x, layer, relu, residual in (a, b):
+        op = _Operands(x, layer)
+        out = torch.empty((op.B, op.cout, op.H, op.W), device=op.device, dtype=torch.float32)
+        if residual is not None:
+            if tuple(residual.shape) != tuple(out.shape):
+                raise ValueError("conv2d_fused_pair: residual shape %s != result shape %s" % (tuple(residual.shape), tuple(out.shape)))
+            residual = residual if _dense(residual) else residual.contiguous()
+            _ffi.require_gpu(residual)
+            _ffi.require_no_grad(residual)
+        descs.append(_desc(op, out, relu=relu, epilogue=3 if residual is not None else 0, e0=residual))
+        res.append(out)
+        passes = op.passes
+    _launch_pair(descs[0], descs[1], passes, res[0])
+    return res
+
+
 def conv2d_gate_zr_pair(a, b):
     """conv2d_gate_zr for two independent GRUs in one launch.  a, b = (x, zr_layer, cz, cr, h);
     returns ((z_a, rh_a), (z_b, rh_b))."""

@@ -15,7 +15,8 @@ import torch.nn.functional as F
 from . import _ffi
 import os
 
-from .conv import _CACHE_LOCK, conv2d, conv2d_fused, conv2d_stats, fused_eligible, stats_eligible
+from .conv import (_CACHE_LOCK, conv2d, conv2d_fused, conv2d_fused_pair, conv2d_pair, conv2d_stats, fused_eligible,
+                   pair_eligible, stats_eligible)
 
 #: DKT_FUSE_ENCODER=0: separate normalise / residual-join passes around the encoders' convolutions (A/B switch)
 FUSE_ENCODER = os.environ.get("DKT_FUSE_ENCODER", "1") != "0"
@@ -313,6 +314,70 @@ def _init_like_reference(module):
                 nn.init.constant_(m.bias, 0)
 
 
+#: the two output heads of a scale (hidden state, context; core/extractor.py:246-266) share their launches: both first
+#: layers read the same tensor -- ONE convolution with the outputs concatenated --, the later layers run as pairs
+#: (dkt_conv2d_f16s_pair).  Three launches per scale instead of six on a chain of small, latency-bound launches
+PAIR_HEADS = True
+
+
+def _merged_outputs(layers):
+    """One layer computing the outputs of `layers` (same input, same filter geometry) side by side; cached on the first."""
+    with _CACHE_LOCK:
+        key = tuple(_tensor_key(t) for l in layers for t in (l.weight, l.bias))
+        cache = layers[0].__dict__.setdefault("_dkt_merged", {})
+        slot = str(layers[0].weight.device)
+        hit = cache.get(slot)
+        if hit is not None and hit.key == key:
+            return hit
+        m = _Folded()
+        with torch.no_grad():
+            m.weight = torch.cat([l.weight.detach().float() for l in layers], 0).contiguous()
+            m.bias = torch.cat([(l.bias.detach().float() if l.bias is not None else
+                                 torch.zeros(l.weight.shape[0], device=l.weight.device)) for l in layers], 0).contiguous()
+        m.padding, m.stride, m.dilation, m.groups = layers[0].padding, layers[0].stride, layers[0].dilation, layers[0].groups
+        m.key = key
+        cache[slot] = m
+        return m
+
+
+def _same_geometry(a, b):
+    return (tuple(a.weight.shape[1:]) == tuple(b.weight.shape[1:]) and tuple(a.padding) == tuple(b.padding)
+            and tuple(a.stride) == tuple(b.stride) == (1, 1) and tuple(a.dilation) == tuple(b.dilation) == (1, 1)
+            and a.groups == b.groups == 1)
+
+
+def paired_heads(heads, x):
+    """[head(x) for head in heads] for the context encoder's two heads of one scale, in shared launches; None when the pair
+    does not have the expected form (then the caller runs them one after the other)."""
+    if not (PAIR_HEADS and FUSE_ENCODER and len(heads) == 2 and _hip_ok(x)):
+        return None
+    if all(isinstance(h, nn.Conv2d) for h in heads):                       # the 1/16 scale: one 3x3 layer per head
+        a, b = heads
+        if not (_same_geometry(a, b) and a.padding_mode == b.padding_mode == 'zeros'
+                and not (torch.is_grad_enabled() and (a.weight.requires_grad or b.weight.requires_grad))):
+            return None
+        y = conv2d(x, _merged_outputs([a, b]))
+        return list(y.split([a.weight.shape[0], b.weight.shape[0]], dim=1))
+    if not all(isinstance(h, nn.Sequential) and len(h) == 2 and isinstance(h[0], ResidualBlock) and isinstance(h[1], nn.Conv2d)
+               for h in heads):
+        return None
+    (ra, fa), (rb, fb) = heads
+    if ra.downsample is not None or rb.downsample is not None or any(p.requires_grad and torch.is_grad_enabled()
+                                                                     for h in heads for p in h.parameters()):
+        return None
+    if not all(_foldable(r.conv1, r.norm1, x) and _foldable(r.conv2, r.norm2, x) for r in (ra, rb)):
+        return None
+    a1, b1 = _folded(ra.conv1, ra.norm1), _folded(rb.conv1, rb.norm1)
+    a2, b2 = _folded(ra.conv2, ra.norm2), _folded(rb.conv2, rb.norm2)
+    if not (_same_geometry(a1, b1) and pair_eligible(a2, b2) and fused_eligible(a2) and fused_eligible(b2) and pair_eligible(fa, fb)
+            and a2.weight.shape[0] == x.shape[1] == b2.weight.shape[0] and fa.padding_mode == fb.padding_mode == 'zeros'):
+        return None
+    na = a1.weight.shape[0]
+    y = conv2d(x, _merged_outputs([a1, b1]), relu=True)                    # relu(norm1(conv1(x))) of both blocks
+    ya, yb = conv2d_fused_pair((y[:, :na], a2, True, x), (y[:, na:], b2, True, x))      # relu(x + relu(norm2(conv2(.))))
+    return conv2d_pair((ya, fa, False), (yb, fb, False))
+
+
 class _Trunk(nn.Module):
     """conv1/norm1 + layer1..3, shared by both encoders (1/2^downsample resolution)."""
 
@@ -455,6 +520,12 @@ class MultiBasicEncoder(_Trunk):
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init_like_reference(self)
 
+    @staticmethod
+    def _heads(heads, x):
+        """[f(x) for f in heads] (core/extractor.py:284-296), the two heads of a scale in shared launches where possible."""
+        outs = paired_heads(list(heads), x)
+        return outs if outs is not None else [f(x) for f in heads]
+
     def _heads_on_streams(self, x, num_layers, post):
         """The output heads of the three scales beside the trunk's coarse stages: the 1/8 and 1/16 layers are a few
         dozen tiles each -- 30 us per layer whatever their size -- and left ~0.6 ms of the pair with one such kernel at
@@ -464,15 +535,15 @@ class MultiBasicEncoder(_Trunk):
         sa, sb = _side_stream(x.device, slot=2), _side_stream(x.device, slot=3)
         sa.wait_stream(main)
         with torch.cuda.stream(sa):
-            s08 = post(0, [f(x) for f in self.outputs08])
+            s08 = post(0, self._heads(self.outputs08, x))
         y = self.layer4(x)
         sb.wait_stream(main)
         with torch.cuda.stream(sb):
-            s16 = post(1, [f(y) for f in self.outputs16])
+            s16 = post(1, self._heads(self.outputs16, y))
         scales = [s08, s16]
         if num_layers >= 3:
             z = self.layer5(y)
-            scales.append(post(2, [f(z) for f in self.outputs32]))
+            scales.append(post(2, self._heads(self.outputs32, z)))
         main.wait_stream(sa)
         main.wait_stream(sb)
         for t in _tensors_of(s08) + _tensors_of(s16):    # allocated on the side streams, consumed on this one from here on
@@ -491,13 +562,13 @@ class MultiBasicEncoder(_Trunk):
         if CNET_STREAMS and num_layers >= 2 and _hip_ok(x) and not torch.cuda.is_current_stream_capturing():
             scales = self._heads_on_streams(x, num_layers, post)
         else:
-            scales = [post(0, [f(x) for f in self.outputs08])]
+            scales = [post(0, self._heads(self.outputs08, x))]
             if num_layers >= 2:
                 y = self.layer4(x)
-                scales.append(post(1, [f(y) for f in self.outputs16]))
+                scales.append(post(1, self._heads(self.outputs16, y)))
             if num_layers >= 3:
                 z = self.layer5(y)
-                scales.append(post(2, [f(z) for f in self.outputs32]))
+                scales.append(post(2, self._heads(self.outputs32, z)))
         if dual_inp:
             scales.append(v)
         return tuple(scales)

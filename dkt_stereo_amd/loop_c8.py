@@ -19,7 +19,7 @@ from . import conv_c8 as c8
 from .update import interp, pool2x, _leading_outputs
 
 #: tile shapes (conv_c8.hip c8_dispatch) per layer class
-_CFG = dict(zr08=1, q08=2, zr16=4, q16=4, head=2, enc=3, c2=3)
+_CFG = dict(zr08=1, q08=2, zr16=4, q16=4, head=2, enc=3, c2=4)
 #: flow head with the hidden tensor reduced in conv1's epilogue (FUSE_HEAD = False: hidden tensor + few-output kernel)
 FUSE_HEAD = True
 

@@ -14,6 +14,9 @@ if len(sys.argv) > 1 and "=" in sys.argv[1]:
         if k.startswith("model."):
             import dkt_stereo_amd.raft_stereo as rs
             setattr(rs.RAFTStereo, k[6:], int(v))
+        elif k.startswith("ex."):
+            import dkt_stereo_amd.extractor as ex
+            setattr(ex, k[3:], type(getattr(ex, k[3:]))(int(v)))
         elif k.isupper():
             setattr(lp, k, type(getattr(lp, k))(int(v)))
         else:
