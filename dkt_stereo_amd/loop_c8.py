@@ -16,7 +16,7 @@ import torch
 from . import _ffi
 from . import conv as _conv
 from . import conv_c8 as c8
-from .update import interp, pool2x, _leading_outputs
+from .update import interp, pool2x, _leading_outputs, _scaled_layer
 
 #: tile shapes (conv_c8.hip c8_dispatch) per layer class
 _CFG = dict(zr08=1, q08=2, zr16=4, q16=4, head=2, enc=3, c2=4)
@@ -112,6 +112,10 @@ class C8Loop:
         self.graph_n = None              # [parity] GRAPH_UNITS units
         self.graph_last = None           # [parity] the final unit of a pair
         self.front = bool(FRONT) and self._front_supported(st)
+        mask = getattr(ub, "mask", None)               # (IGEV's mask features are computed by its caller)
+        self.mask_head = mask if (mask is not None and len(mask) == 3 and isinstance(mask[0], torch.nn.Conv2d)
+                                  and tuple(mask[0].weight.shape[2:]) == (3, 3) and tuple(mask[2].weight.shape[2:]) == (1, 1)) else None
+        self.mask_out = None
         self.par = 0                     # which of self.cx holds the current x coordinate
         self.cx = None
         self.calibrated = not AUTOSCALE
@@ -124,6 +128,7 @@ class C8Loop:
     def capture(self, st, capture_graph):
         """Captures one unit, the final unit, and GRAPH_UNITS units back to back (capturing records, it does not execute) --
         with the fused front once per parity of the coordinate buffer the sequence starts from."""
+        self._mask(st)          # eager once: the final unit's own layers are packed (with the calibrated scales) outside the capture
         torch.cuda.synchronize()
         keep = self.par
         self.graph, self.graph_last, self.graph_n = {}, {}, {}
@@ -339,6 +344,16 @@ class C8Loop:
             self.cx[0].copy_(self.cx[1])          # the pair's final coordinate lives in st["coords1"]
             self.par = 0
 
+    def _mask(self, st):
+        """0.25 * mask(net[0]) (core/update.py:107-110, :136): the 3x3 layer reads the C8S twin of the final hidden state, the
+        factor is folded into the 1x1 layer's weights (a power of two: the same bits)."""
+        mh = self.mask_head
+        if mh is None:
+            self.mask_out = None
+            return
+        hid = c8.conv2d_c8([self.hc8[0]], mh[0], relu=True, cfg=1)
+        self.mask_out = _conv.conv2d(hid, _scaled_layer(mh[2], 0.25), out=self.mask_out)
+
     def _mid(self, st):
         n0, n1, n2 = st["net"]
         if PAIR_RESAMPLE:
@@ -360,7 +375,20 @@ class C8Loop:
         the fork alone).  `last`: the pair's final iteration (nothing of a next one is started)."""
         self._gru_pair(st)
         if last:
-            self._head(st)
+            # the up-sampling mask head reads the final hidden state only: beside the flow head, on the forked stream
+            if FORK and self.mask_head is not None:
+                from .update import _side_stream
+                dev = st["net"][0].device
+                main = torch.cuda.current_stream(dev)
+                side = _side_stream(dev, slot=0)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._mask(st)
+                self._head(st)
+                main.wait_stream(side)
+            else:
+                self._head(st)
+                self._mask(st)
             return
         front = self.front and FUSE_HEAD
         if FORK:

@@ -573,7 +573,10 @@ class RAFTStereo(nn.Module):
                 lp.capture(st, capture_graph)        # (capturing does not execute: still one unit done)
             if iters > done:
                 lp.replay(iters - done, last=True)
-            # up-sampling mask head (core/update.py:107-110, :136) from the final hidden state: its 3x3 layer reads the C8S twin
+            # up-sampling mask head (core/update.py:107-110, :136) from the final hidden state: the final unit computes it
+            # beside the flow head (loop_c8.C8Loop._mask)
+            if lp.mask_out is not None:
+                return lp.mask_out
             from . import conv_c8
             return .25 * conv2d(conv_c8.conv2d_c8([lp.hc8[0]], ub.mask[0], relu=True, cfg=1), ub.mask[2])
 

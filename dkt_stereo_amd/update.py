@@ -24,6 +24,8 @@ import os
 import threading
 from types import SimpleNamespace
 
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -193,6 +195,30 @@ class _LayerView:
     @dkt_in_exp.setter
     def dkt_in_exp(self, e):
         self._parent.dkt_in_exp = e
+
+
+class _ScaledLayer(_LayerView):
+    """`layer` with weight and bias multiplied by a power of two: scale * layer(x) in the layer's own launch (exact in fp32,
+    so bit-identical to scaling the result -- the reference's `.25 * self.mask(net)`, core/update.py:136)."""
+
+    def __init__(self, layer, scale):
+        super().__init__(layer, layer.weight.shape[0])
+        with torch.no_grad():
+            self.weight = (layer.weight.detach() * scale).contiguous()
+            self.bias = None if layer.bias is None else (layer.bias.detach() * scale).contiguous()
+        self._key = self._key[:3] + (("scale", scale),)
+
+
+def _scaled_layer(layer, scale):
+    m, e = math.frexp(scale)
+    if m != 0.5:
+        raise ValueError("_scaled_layer: %r is not a power of two" % (scale,))
+    key = (layer.weight.data_ptr(), layer.weight._version,
+           None if layer.bias is None else (layer.bias.data_ptr(), layer.bias._version), ("scale", scale))
+    view = layer.__dict__.get("_dkt_scaled")
+    if view is None or view._key != key:
+        view = layer.__dict__["_dkt_scaled"] = _ScaledLayer(layer, scale)
+    return view
 
 
 def _leading_outputs(layer, n):
