@@ -394,6 +394,8 @@ def main():
         torch.cuda.synchronize()
         hot_ms = e0.elapsed_time(e1)
 
+    lp_ = (model._graph_state or {}).get("c8")
+    front_used = bool(lp_ is not None and getattr(lp_, "front", False))
     precision = {"operand_bits": {"f16x3": 22, "f16x2": 11, "f16": 11, "miopen": 24}[_conv.get_backend()],
                  "accumulate": "fp32",
                  "conv_rel_err_vs_fp64": conv_precision(dev),
@@ -509,6 +511,10 @@ def main():
                                                       if default_shape and traffic else None),
                             "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
                             "launches_timed": len(look_ms),
+                            # where the loop runs it (this entry times the stand-alone launch of the same lookup + 1x1 layer)
+                            "in_loop": ("since round 4 inside motion_front_kernel (dkt_motion_front_c8: the coordinate update "
+                                        "behind the flow head + this lookup and 1x1 layer + the motion encoder's 7x7 stem, one "
+                                        "launch per iteration; profiles/r04_pair_breakdown.txt)" if front_used else "its own launch"),
                             # the same kernel as the loop runs it (rocprofv3 kernel trace of this command, kept under profiles/)
                             "in_pipeline_from_profiles": ({"avg_launch_us": traffic.get("lookup_in_pipeline_us"),
                                                            "frac": alg / (traffic["lookup_in_pipeline_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,

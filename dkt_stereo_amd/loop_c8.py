@@ -39,6 +39,8 @@ RANGE_LO, RANGE_HI = 6, 14
 #: the middle GRU's chain of the next iteration on a second stream beside the head and the motion encoder (DKT_C8_FORK=0: one stream)
 #: (=2: also the motion encoder's 7x7 stem beside the lookup on a third stream -- measured 0.25 ms per pair SLOWER, kept for A/B)
 FORK = int(os.environ.get("DKT_C8_FORK", "1"))
+#: the prologue's motion features beside its hidden-state chain (see C8Loop.prologue)
+PROLOGUE_FORK = True
 #: the coordinate update behind the flow head, the lookup + convc1 and the motion encoder's 7x7 stem as ONE launch
 #: (dkt_motion_front_c8; the x coordinate alternates between two buffers, see C8Loop.unit)
 FRONT = True
@@ -427,10 +429,22 @@ class C8Loop:
         self.par = 0
         for lvl, n in enumerate(st["net"]):
             c8.pack(n, self.hc8[lvl])
+        if FORK and PROLOGUE_FORK:
+            # the motion features of iteration 0 need the correlation volume and the initial coordinates only: beside the
+            # hidden-state chain (pack, pool, coarsest and middle GRU) instead of behind it
+            from .update import _side_stream
+            main = torch.cuda.current_stream(n0.device)
+            side = _side_stream(n0.device, slot=0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._motion(st)
         c8.pool2x_c8(n1, self.pool1)
         self._gru(2, self.grus[2], st, [self.pool1], 4, 4)
         self._mid(st)
-        self._motion(st)
+        if FORK and PROLOGUE_FORK:
+            main.wait_stream(side)
+        else:
+            self._motion(st)
 
 
 class C8LoopIGEV(C8Loop):
