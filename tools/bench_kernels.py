@@ -443,7 +443,21 @@ def bench_c8():
         coords[:, 0] = xs - 20.3 - 3.0 * torch.sin(torch.arange(H, device=DEV).float() / 9.0).view(1, H, 1)
         dst = c8.ActC8(B, 64, H, W, DEV)
         report("lookup + convc1 -> C8S B=%d smooth" % B, timeit(lambda: blk.lookup_conv1x1(coords, c1, out_c8=dst), n=200), bytes_=B * H * W * 420)
+        # round 4: the motion encoder's front as one launch (coordinate update + that lookup / 1x1 layer + the 7x7 stem)
+        hcb = c8.pack(torch.tanh(torch.randn(B, 128, H, W, device=DEV)))
+        planes, n_co = c8.head_planes([hcb], h1, _leading_outputs(h2l, 1), cfg=2)
+        x_old, x_new, x0 = coords[:, :1].clone(), torch.empty(B, 1, H, W, device=DEV), coords[:, :1].clone()
+        fl2, flo2 = torch.zeros(B, 2, H, W, device=DEV), c8.ActC8(B, 64, H, W, DEV)
+        report("motion front B=%d: finish + lookup + convc1 + stem7 -> C8S, one launch" % B,
+               timeit(lambda: c8.motion_front(blk, planes, n_co, _leading_outputs(h2l, 1).bias, x_old, x_new, x0, fl2, c1, dst, st7, flo2), n=200),
+               bytes_=B * H * W * (420 + 18 * 4 + 12 + 256))
         del blk, f1, f2_, dst
+    u2, p1 = c8.ActC8(1, 128, 92, 156, DEV), c8.ActC8(1, 128, 46, 78, DEV)
+    n2 = torch.randn(1, 128, 46, 78, device=DEV)
+    report("pool2x(1/4) | interp(1/16 -> 1/8) -> C8S, one launch", timeit(lambda: c8.resample_pair_c8(("pool", n0, p0), ("interp", n2, u2)), n=200),
+           bytes_=(n0.numel() + n2.numel()) * 4 + 2 * 92 * 156 * 128 * 4)
+    report("interp(1/8 -> 1/4) | pool2x(1/8) -> C8S, one launch", timeit(lambda: c8.resample_pair_c8(("interp", n1, u1), ("pool", n1, p1)), n=200),
+           bytes_=2 * n1.numel() * 4 + (n0.numel() + 46 * 78 * 128) * 4)
     # group-wise correlation: exact VALU kernel vs the banded MFMA product
     for name, C, G_, h, w in (("IGEV 96ch G=8", 96, 8, 184, 312), ("GwcNet 320ch G=40", 320, 40, 136, 240)):
         a, b = (torch.randn(1, C, h, w, device=DEV) for _ in range(2))
