@@ -10,7 +10,7 @@ tests) python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/${R}_gputests.txt ;;
 prof)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof -o bench -- python bench.py --steps 3 --warmup 2 --skip-cpu-baseline > $O/${R}_prof_bench.log 2>&1
   T=$(find $O/${R}_prof -name "*kernel_trace.csv" | head -1)
-  python tools/rocprof_pair_breakdown.py $T --pair 3 --phases --timeline 10 --encoders > $O/${R}_pair_breakdown.txt 2>&1
+  python tools/rocprof_pair_breakdown.py $T --pair 6 --phases --timeline 10 --encoders > $O/${R}_pair_breakdown.txt 2>&1
   python tools/rocprof_summary.py $T > $O/${R}_kernels.txt 2>&1
   cp $(find $O/${R}_prof -name "*kernel_stats.csv" | head -1) $O/${R}_bench_kernel_stats.csv
   rm -rf $O/${R}_prof ;;

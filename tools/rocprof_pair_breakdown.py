@@ -39,10 +39,18 @@ def main():
                                              r.get("Grid_Size_X", r.get("Grid_Size", ""))))
         print("# iteration wall: %.1f us" % ((int(it[-1]["End_Timestamp"]) - t0) / 1e3))
     if a.phases:
+        # Since round 4 the correlation build runs inside the encoder phase (on the feature encoder's stream), so the pair is
+        # cut at the loop's own first launch -- the pack of the hidden states into C8S (act_c8_pack_kernel) -- when there is one.
+        packs = [i for i, r in enumerate(rows) if "act_c8_pack" in r["Kernel_Name"]]
+        start = next((i for i in packs if i >= lo), lo)
+        nxt = next((i for i in packs if i > start + 8), None)
+        if nxt is None or not packs:
+            start, nxt = lo, hi
+        win = rows[start:nxt]
         lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"] or "motion_front" in r["Kernel_Name"]]
         end = lk[-1] + (lk[-1] - lk[-2])          # the last iteration is as long as the one before it
-        table(win[:end], a.top, "GRU loop (corr build + %d iterations)" % len(lk))
-        table(win[end:], a.top, "upsampling + encoders")
+        table(win[:end], a.top, "GRU loop (prologue + %d iterations)" % (len(lk) + 1))
+        table(win[end:], a.top, "upsampling + encoders + correlation build of the next pair")
         if a.encoders:
             t0 = int(win[end]["Start_Timestamp"])
             print("# dispatches of the up-sampling + encoder phase (start offset us, duration us, end offset us, queue, kernel, grid)")
