@@ -109,8 +109,6 @@ class RAFTStereo(nn.Module):
 
     #: run fnet and cnet on two HIP streams (DKT_ENCODER_STREAMS=0 disables)
     encoder_streams = os.environ.get("DKT_ENCODER_STREAMS", "1") != "0"
-    #: launch order of the two encoders on their two streams (see _encode)
-    encoder_order = 0
 
     #: replay the encoder pass (normalisation, fnet || cnet, context split: ~110 launches, two streams) from a
     #: captured HIP graph as well: launched eagerly, the host needs 2.5 ms to enqueue fnet before cnet's first
@@ -119,7 +117,7 @@ class RAFTStereo(nn.Module):
     graph_encoders = False
 
     def _encoder_fingerprint(self):
-        fp = [(_conv.get_backend(), _extractor.FUSE_ENCODER, self.encoder_streams, self.encoder_order)]
+        fp = [(_conv.get_backend(), _extractor.FUSE_ENCODER, self.encoder_streams)]
         for mod in (self.fnet, self.cnet, self.context_zqr_convs):
             for t in list(mod.parameters()) + list(mod.buffers()):
                 fp.append((t.data_ptr(), t._version))
@@ -234,28 +232,11 @@ class RAFTStereo(nn.Module):
             # small layers of either one leave CUs idle); joined before anything consumes fmaps
             main = torch.cuda.current_stream(image1.device)
             side = _side_stream(image1.device)
-            if self.encoder_order == 1:
-                # the context encoder is enqueued first (it ends in a chain of small launches that leaves the device idle;
-                # started late, that tail lies behind the feature encoder's last layer instead of beside its big ones)
-                forked = torch.cuda.Event()
-                forked.record(main)
-                cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
-                side.wait_event(forked)
-                with torch.cuda.stream(side):
-                    fmap1, fmap2 = split(self.fnet(fnet_in))
-                    self._prebuild(image1, fmap1, fmap2)
-            elif self.encoder_order == 2:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
                 fmap1, fmap2 = split(self.fnet(fnet_in))
                 self._prebuild(image1, fmap1, fmap2)
-            else:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    fmap1, fmap2 = split(self.fnet(fnet_in))
-                    self._prebuild(image1, fmap1, fmap2)
-                cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
+            cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
             main.wait_stream(side)
         else:
             self._prebuilt = None

@@ -329,3 +329,55 @@ def test_motion_front_equals_the_three_launches(B, H, W, radius):
         assert torch.equal(cor.t, cor_ref.t) and torch.equal(flo.t, flo_ref.t)
     with pytest.raises(ValueError):
         c8.motion_front(blk, planes, n_co, last.bias, c_old[:, :1], c_old[:, :1], coords0[:, :1], flow, convc1, cor, convf1, flo)
+
+
+@torch.no_grad()
+def test_encoder_outputs_in_place_and_prebuilt_volume_change_nothing():
+    """From the second forward of a shape on, encode() writes the hidden states / context terms into the captured loop's state
+    buffers and rebuilds the loop's correlation block on the feature encoder's stream (RAFTStereo.adopt_encoder_outputs,
+    prebuild_corr): same disparity, bit for bit, as a model that keeps private tensors and builds the volume in iterate();
+    the aliasing is what it claims to be; another pair through the same state stays right."""
+    import _synth
+    from test_gpu_parity import G, _raft
+    H, W = 384, 640                                  # 96 x 160 at 1/4: the C8S loop (>= 24 000 quarter-resolution pixels is not
+    a, _ = _raft()                                   # needed for the aliasing itself -- the round-2 loop shares the state logic)
+    b, _ = _raft()
+    b.adopt_encoder_outputs = b.prebuild_corr = False
+    pairs = [tuple(G(t) for t in _synth.image_pair(s, 1, H, W, 12 + 9 * s)) for s in (0, 1, 2)]
+    for k, (i1, i2) in enumerate(pairs + pairs[:1]):
+        ra, rb = a(i1, i2, iters=6, test_mode=True), b(i1, i2, iters=6, test_mode=True)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]), k
+    st = a._graph_state
+    f1, f2, net, inp = a.encode(*pairs[1])
+    assert [t.data_ptr() for t in net] == [t.data_ptr() for t in st["net"]]
+    assert [t.data_ptr() for sc in inp for t in sc] == [t.data_ptr() for sc in st["inp"] for t in sc]
+    assert a._prebuilt is st["corr"]
+    n2 = b.encode(*pairs[1])[2]
+    assert [t.data_ptr() for t in n2] != [t.data_ptr() for t in b._graph_state["net"]]
+    for x, y in zip(net, n2):
+        assert torch.equal(x, y)
+    lo, up = a.iterate(f1, f2, net, inp, 6)
+    assert torch.equal(up, b(*pairs[1], iters=6, test_mode=True)[1])
+
+
+@torch.no_grad()
+def test_paired_context_heads_equal_the_single_launches():
+    """extractor.paired_heads (merged first layers, paired residual / output layers; core/extractor.py:246-266, :284-296) ==
+    the heads run one after the other, for the three scales' head shapes."""
+    import _synth
+    from test_gpu_parity import G, _raft
+    from dkt_stereo_amd import extractor as ex
+    m, _ = _raft()
+    i1, _ = _synth.image_pair(4, 2, 192, 320, 12)
+    x = (2 * (G(i1) / 255.0) - 1.0).contiguous()
+    keep = ex.PAIR_HEADS
+    try:
+        ex.PAIR_HEADS = True
+        got = m.cnet(x, num_layers=3)
+        ex.PAIR_HEADS = False
+        want = m.cnet(x, num_layers=3)
+    finally:
+        ex.PAIR_HEADS = keep
+    for g, w in zip(got, want):
+        for u, v in zip(g, w):
+            assert torch.equal(u, v)
