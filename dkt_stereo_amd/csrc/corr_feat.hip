@@ -562,7 +562,7 @@ __device__ __forceinline__ void corr_feat64_body(const CorrFeatArgs &a, long bx,
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void corr_feat64_kernel(CorrFeatArgs a) {
+__global__ __launch_bounds__(256, 8) void corr_feat64_kernel(CorrFeatArgs a) {
     corr_feat64_body<R>(a, (long)blockIdx.x, (int)blockIdx.y,
                         [&](int b, long p, bool, int) -> float { return a.coords_x[(size_t)b * a.coords_bstride + p]; });
 }
