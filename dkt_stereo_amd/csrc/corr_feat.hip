@@ -421,8 +421,11 @@ __global__ __launch_bounds__(256) void corr_feat16_kernel(CorrFeatArgs a) {
 template <int R, class CX>
 __device__ __forceinline__ void corr_feat64_body(const CorrFeatArgs &a, long bx, int b, CX coord) {
     constexpr int K = 2 * R + 1;
-    constexpr int PITCH = 65;          // (80 -- k rows 16 banks apart -- measured the same: LDS is not the limiter)
-    __shared__ float vs[4 * K * PITCH];
+    // sample (level g, tap k) = GEMM row kk = g K + k of pixel px lives at vs[((kk & 3) * 64 + px) * VP + (kk >> 2)]: phase 2's
+    // lane (pixel, q = kk & 3) finds its NS = K values of a tile in one 48-byte run (three ds_read_b128 instead of K ds_read_b32)
+    constexpr int VP = 12;
+    static_assert((4 * K + 3) / 4 <= VP, "row pitch holds the k steps");
+    __shared__ __attribute__((aligned(16))) float vs[4 * 64 * VP];
     const int lane = threadIdx.x & 63;
     const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nseg = (a.W1 + 63) / 64;
@@ -492,7 +495,7 @@ __device__ __forceinline__ void corr_feat64_body(const CorrFeatArgs &a, long bx,
             }
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) vs[(g * K + k) * PITCH + lane] = v[k];
+        for (int k = 0; k < K; ++k) vs[(((g * K + k) & 3) * 64 + lane) * VP + ((g * K + k) >> 2)] = v[k];
         if (a.tap && live) {
             float *t = a.tap + (size_t)b * a.tap_bstride + p;
 #pragma unroll
@@ -508,11 +511,24 @@ __device__ __forceinline__ void corr_feat64_body(const CorrFeatArgs &a, long bx,
     f32x4_ acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    // two pixel tiles at a time (24 fragment registers: all four would not fit the 64 the occupancy allows)
 #pragma unroll
-    for (int sidx = 0; sidx < NS; ++sidx) {
-        const int kk = 4 * sidx + q;
+    for (int t0 = 0; t0 < 4; t0 += 2) {
+        float bs[2][VP];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[sidx], vs[kk * PITCH + 16 * t + j], acc[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+            const float4 *row = (const float4 *)(vs + (q * 64 + 16 * (t0 + t) + j) * VP);
+#pragma unroll
+            for (int i = 0; i < VP / 4; ++i) {
+                const float4 f = row[i];
+                bs[t][4 * i] = f.x; bs[t][4 * i + 1] = f.y; bs[t][4 * i + 2] = f.z; bs[t][4 * i + 3] = f.w;
+            }
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t0 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[sidx], bs[t][sidx], acc[t0 + t], 0, 0, 0);
+        }
     }
     float bv[4];
 #pragma unroll
