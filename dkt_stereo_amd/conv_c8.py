@@ -101,6 +101,25 @@ class _PackedC8:
     __slots__ = ("key", "img", "inv_scale", "bias")
 
 
+#: packed images kept per (layer, device, operand split): one per set of operand scales in use.  Two captured loops over the
+#: same modules (two threads driving replicas, nn.parallel.replicate shares every layer object) may have picked different
+#: activation scales; with a single entry each of them would re-pack on every call, and the other's captured graph would keep
+#: the address of a freed image.  Entries of other weight versions are dropped first.
+_PACK_KEEP = 6
+
+
+def _cache_get(cache, slot, key):
+    for p in cache.get(slot, ()):
+        if p.key == key:
+            return p
+    return None
+
+
+def _cache_put(cache, slot, p, n_weight_keys):
+    keep = [q for q in cache.get(slot, ()) if q.key[:n_weight_keys] == p.key[:n_weight_keys]]
+    cache[slot] = (keep + [p])[-_PACK_KEEP:]
+
+
 def _in_scale_vector(seg_lists, device):
     """1 / scale per input channel for operands whose channel_scales() are `seg_lists` (None when every scale is 1)."""
     segs = [sg for lst in seg_lists for sg in lst]
@@ -120,8 +139,8 @@ def packed_weights(layer, src_channels, src_scales=None):
         key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), tuple(src_channels), scales)
         cache = layer.__dict__.setdefault("_dkt_packed_c8", {})
         slot = (str(w.device), tuple(src_channels))
-        hit = cache.get(slot)
-        if hit is not None and hit.key == key:
+        hit = _cache_get(cache, slot, key)
+        if hit is not None:
             return hit
         cout, cin, kh, kw = w.shape
         if (kh, kw) != (3, 3) or cin != sum(src_channels):
@@ -145,7 +164,7 @@ def packed_weights(layer, src_channels, src_scales=None):
         p.inv_scale = 2.0 ** -e
         p.bias = None if b is None else b.detach().float().contiguous()
         p.key = key
-        cache[slot] = p
+        _cache_put(cache, slot, p, 3)
         return p
 
 
@@ -185,8 +204,8 @@ def gru_packed(gru, x_channels, h_scales=None, x_scales=None):
         key = tuple((p.data_ptr(), p._version) for p in ps) + (tuple(x_channels), hs, xs)
         cache = gru.__dict__.setdefault("_dkt_gru_c8", {})
         slot = (str(ps[0].device), tuple(x_channels))
-        hit = cache.get(slot)
-        if hit is not None and hit.key == key:
+        hit = _cache_get(cache, slot, key)
+        if hit is not None:
             return hit
         wz, wr, wq = (p.detach().float() for p in ps[:3])
         ch, cin = int(wz.shape[0]), int(wz.shape[1])
@@ -202,7 +221,7 @@ def gru_packed(gru, x_channels, h_scales=None, x_scales=None):
         p.wq, p.inv_q = _pack_raw(wq2, list(x_channels) + [ch])
         p.bz, p.br, p.bq = (b.detach().float().contiguous() for b in ps[3:])
         p.key = key
-        cache[slot] = p
+        _cache_put(cache, slot, p, 6)
         return p
 
 

@@ -27,6 +27,9 @@ FUSE_HEAD = True
 #: round 4: the finest GRU (with the coarsest one of the next iteration riding along) as ONE launch per step (csrc/gru_c8.hip:
 #: z|r -> gates -> q -> h' per tile, neighbour flags instead of a kernel boundary); DKT_C8_FUSE_GRU=0: two launches per step
 FUSE_GRU = os.environ.get("DKT_C8_FUSE_GRU", "1") != "0"
+#: 8 x 32 tiles of the finest level (x batch) from which the one-launch form is taken; below: two launches on the tiles of _CFG_SMALL
+FUSE_GRU_MIN_TILES = 128
+_CFG_SMALL = dict(zr08=4, q08=4)
 
 #: round 4: every C8S tensor of the loop carries a power-of-two scale picked from the magnitudes one trial unit produces
 #: (C8Loop.calibrate): max |x * scale| lands in [2^SCALE_EXP, 2^(SCALE_EXP + 1)), i.e. 5 bits below fp16's overflow and with
@@ -52,9 +55,10 @@ HEAD_FIRST = True
 #: the bulk of the iterations is replayed GRAPH_UNITS units at a time (a one-unit graph serves the remainder)
 GRAPH_UNITS = max(1, int(os.environ.get("DKT_C8_GRAPH_UNITS", "8")))
 
-#: quarter-resolution pixels (per pair) from which the loop takes this path: the C8S kernel's tiles are 8 rows x 32 columns
-#: x 64-256 channels, smaller images leave most CUs without one (256 x 512: 7.4 ms against 5.4 on the round-2 kernels)
-MIN_PIXELS = int(os.environ.get("DKT_C8_MIN_PIXELS", "24000"))
+#: quarter-resolution pixels (per pair) from which the loop takes this path.  Round 4: every size does (small images on the
+#: two-launch form of the finest GRU with 4-row tiles, see C8Loop.__init__): 256 x 512 / 32 iterations 9.5 ms against 12.1 on
+#: the round-2 kernels; the variable remains as the A/B handle
+MIN_PIXELS = int(os.environ.get("DKT_C8_MIN_PIXELS", "0"))
 
 
 def eligible(model, shape=None):
@@ -62,16 +66,20 @@ def eligible(model, shape=None):
     return _eligible_block(model.update_block, shape, 126)
 
 
+#: IGEV keeps the round-2 loop below this many quarter-resolution pixels (its small shapes have not been measured on this loop)
+IGEV_MIN_PIXELS = 24000
+
+
 def eligible_igev(ub, shape=None):
     """IGEV's update block (meta_arch/igev_stereo/update.py:94-142: gru04 / gru08 / gru16, 127-channel motion encoder,
     one-output disparity head) on this loop."""
-    return (_eligible_block(ub, shape, 127) and all(hasattr(ub, n) for n in ("gru04", "gru08", "gru16", "disp_head"))
-            and ub.disp_head.conv2.weight.shape[0] == 1)
+    return (_eligible_block(ub, shape, 127, max(MIN_PIXELS, IGEV_MIN_PIXELS))
+            and all(hasattr(ub, n) for n in ("gru04", "gru08", "gru16", "disp_head")) and ub.disp_head.conv2.weight.shape[0] == 1)
 
 
-def _eligible_block(ub, shape, enc_out):
+def _eligible_block(ub, shape, enc_out, min_pixels=None):
     a = ub.args
-    if shape is not None and shape[2] * shape[3] < MIN_PIXELS:
+    if shape is not None and shape[2] * shape[3] < (MIN_PIXELS if min_pixels is None else min_pixels):
         return False
     if a.n_gru_layers != 3 or getattr(a, "slow_fast_gru", False) or _conv.get_backend() != "f16x3":
         return False
@@ -108,7 +116,15 @@ class C8Loop:
         # fused ConvGRU launches: per-tile flag words per level, one error word (a neighbour wait that timed out)
         self.gflags = [c8.gru_flags(B, n.shape[2], n.shape[3], dev) for n in (n0, n1, n2)]
         self.err = torch.zeros(1, device=dev, dtype=torch.int32)
-        self.fuse_gru = FUSE_GRU
+        # Tile shapes per layer class, and the form of the finest ConvGRU, by the number of 8 x 32 tiles the level gives: the
+        # one-launch form holds ONE tile per CU through both convolutions, so an image of 32 tiles (256 x 512) keeps 32 CUs busy
+        # for a whole step; below FUSE_GRU_MIN_TILES the step is two launches on 4-row tiles (9.5 ms against 15.0 at
+        # 256 x 512 / 32 iterations, 14.8 against 17.5 at 480 x 640; 544 x 960 -- 136 tiles -- and up: the one launch wins)
+        tiles = B * ((n0.shape[2] + 7) // 8) * ((n0.shape[3] + 31) // 32)
+        self.cfg = dict(_CFG)
+        self.fuse_gru = FUSE_GRU and tiles >= FUSE_GRU_MIN_TILES
+        if not self.fuse_gru and FUSE_GRU:
+            self.cfg.update(zr08=_CFG_SMALL["zr08"], q08=_CFG_SMALL["q08"])
         # captured units, per parity of the coordinate buffer they start from (self.par; always 0 without the fused front)
         self.graph = None                # [parity] one unit
         self.graph_n = None              # [parity] GRAPH_UNITS units
@@ -271,13 +287,13 @@ class C8Loop:
             z = torch.empty_like(h)
             zs.append(z)
             ds.append(c8.desc([self.hc8[lvl], *xs], gru._merged_zr(), out=z, epilogue=1, e0=cz, e1=cr, h=h, out2_c8=self.rh[lvl]))
-        c8.launch_pair(ds[0], ds[1], zs[0], _CFG["zr08"])
+        c8.launch_pair(ds[0], ds[1], zs[0], self.cfg["zr08"])
         ds = []
         for (lvl, gru, xs), z in zip(((0, fine, [self.mf, self.up1]), (2, coarse, [self.pool1])), zs):
             h = st["net"][lvl]
             cq = st["inp"][lvl][2]
             ds.append(c8.desc([self.rh[lvl], *xs], gru.convq, out=h, out_c8=self.hc8[lvl], epilogue=2, e0=cq, e1=z, h=h))
-        c8.launch_pair(ds[0], ds[1], zs[0], _CFG["q08"])
+        c8.launch_pair(ds[0], ds[1], zs[0], self.cfg["q08"])
 
     def _fork_stem(self, ref, fn):
         """The motion encoder's 7x7 stem beside the lookup (independent until convc2 | convf2 joins them): a third stream."""
@@ -307,8 +323,8 @@ class C8Loop:
         enc = self.ub.encoder
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convf2, relu=True, out_c8=self.cf, out_c8_ch0=64)
-        c8.launch_pair(d0, d1, st["flow"], _CFG["c2"])
-        c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["flow"], cfg=_CFG["enc"])
+        c8.launch_pair(d0, d1, st["flow"], self.cfg["c2"])
+        c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["flow"], cfg=self.cfg["enc"])
 
     def _motion(self, st):
         self._motion_front(st)
@@ -327,7 +343,7 @@ class C8Loop:
         fh = self.ub.flow_head
         if front:
             cx = self._coords(st)
-            planes, n_co = c8.head_planes([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), cfg=_CFG["head"])
+            planes, n_co = c8.head_planes([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), cfg=self.cfg["head"])
             enc = self.ub.encoder
             c8.motion_front(st["corr"], planes, n_co, _leading_outputs(fh.conv2, 1).bias, cx[self.par], cx[1 - self.par],
                             st["coords0"][:, :1], st["flow"], enc.convc1, self.cor, enc.convf1, self.flo)
@@ -337,9 +353,9 @@ class C8Loop:
         if FUSE_HEAD:
             # conv2 (x output only: raft_stereo.py:165) from per-tap projections made in conv1's epilogue
             c8.head([self.hc8[0]], fh.conv1, _leading_outputs(fh.conv2, 1), target,
-                    diff=(st["coords0"][:, :1], st["flow"][:, :1]), cfg=_CFG["head"])
+                    diff=(st["coords0"][:, :1], st["flow"][:, :1]), cfg=self.cfg["head"])
         else:
-            c8.conv2d_c8([self.hc8[0]], fh.conv1, relu=True, out=self.hidden, cfg=_CFG["head"])
+            c8.conv2d_c8([self.hc8[0]], fh.conv1, relu=True, out=self.hidden, cfg=self.cfg["head"])
             _conv.conv2d_accumulate(self.hidden, _leading_outputs(fh.conv2, 1), target,
                                     diff=(st["coords0"][:, :1], st["flow"][:, :1]))
         if self.front and self.par:
@@ -363,7 +379,7 @@ class C8Loop:
         else:
             c8.pool2x_c8(n0, self.pool0)
             c8.interp_c8(n2, self.up2)
-        self._gru(1, self.grus[1], st, [self.pool0, self.up2], _CFG["zr16"], _CFG["q16"])
+        self._gru(1, self.grus[1], st, [self.pool0, self.up2], self.cfg["zr16"], self.cfg["q16"])
         if PAIR_RESAMPLE:
             c8.resample_pair_c8(("interp", n1, self.up1), ("pool", n1, self.pool1))
         else:
@@ -479,9 +495,9 @@ class C8LoopIGEV(C8Loop):
         enc = self.ub.encoder
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convd2, relu=True, out_c8=self.cf, out_c8_ch0=64)
-        c8.launch_pair(d0, d1, st["disp"], _CFG["c2"])
-        c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["disp"], cfg=_CFG["enc"])
+        c8.launch_pair(d0, d1, st["disp"], self.cfg["c2"])
+        c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["disp"], cfg=self.cfg["enc"])
 
     def _head(self, st, front=False):
         dh = self.ub.disp_head
-        c8.head([self.hc8[0]], dh.conv1, dh.conv2, st["disp"], cfg=_CFG["head"])      # disp += delta (igev_stereo.py:209)
+        c8.head([self.hc8[0]], dh.conv1, dh.conv2, st["disp"], cfg=self.cfg["head"])      # disp += delta (igev_stereo.py:209)

@@ -225,8 +225,9 @@ def test_hip_graph_replay_matches_eager():
     result on identical encoder outputs: on the first call (capture), on a later call with
     another pair (replay only) and after a shape change (fresh capture).  (The encoders are
     run once per pair and shared: vendor convolutions may pick another algorithm per call.)"""
-    from test_gpu_parity import _raft
+    from test_gpu_parity import _raft, maxabs
     model, _ = _raft()
+    model.use_c8 = False                  # the round-2 loop: its captured iteration IS the plain loop's arithmetic
     model._graph_state = None
     for (h, w, iters, seed, shift) in ((128, 256, 7, 0, 12), (128, 256, 7, 5, 30), (64, 128, 5, 1, 12)):
         i1, i2 = _synth.image_pair(seed, 1, h, w, shift)
@@ -237,6 +238,27 @@ def test_hip_graph_replay_matches_eager():
         lo_g, up_g = model.iterate(fmap1, fmap2, [t.clone() for t in net], inp, iters)
         assert torch.equal(lo_g, lo_e) and torch.equal(up_g, up_e), (h, w, seed)
     assert model._graph_state is not None and model._graph_state["graph"] is not None
+    # the default loop (loop_c8, every size since round 4): replay == the same units launched eagerly, bit for bit; the plain
+    # loop on the round-2 kernels is another summation order of the same split-fp16 products
+    model, _ = _raft()
+    for (h, w, iters, seed, shift) in ((128, 256, 7, 0, 12), (128, 256, 7, 5, 30), (64, 128, 5, 1, 12)):
+        i1, i2 = _synth.image_pair(seed, 1, h, w, shift)
+        fmap1, fmap2, net, inp = model.encode(G(i1), G(i2))
+        net = [t.clone() for t in net]
+        inp = [[t.clone() for t in sc] for sc in inp]
+        model.use_hip_graph = False
+        lo_p, up_p = model.iterate(fmap1, fmap2, [t.clone() for t in net], inp, iters)
+        model.use_hip_graph = True
+        lo_g, up_g = model.iterate(fmap1, fmap2, [t.clone() for t in net], inp, iters)      # first call of a shape: eager unit + capture + replay
+        lo_r, up_r = model.iterate(fmap1, fmap2, [t.clone() for t in net], inp, iters)      # replay only
+        assert model._graph_state.get("c8") is not None and model._graph_state["c8"].graph
+        model.c8_eager = True
+        try:
+            lo_e, up_e = model.iterate(fmap1, fmap2, [t.clone() for t in net], inp, iters)
+        finally:
+            model.c8_eager = False
+        assert torch.equal(lo_g, lo_r) and torch.equal(up_g, up_r) and torch.equal(lo_g, lo_e) and torch.equal(up_g, up_e), (h, w, seed)
+        assert maxabs(up_g, up_p) <= 2e-4 * max(1.0, float(up_p.abs().max())), (h, w, seed)
 
 
 @torch.no_grad()

@@ -151,30 +151,41 @@ def test_raft_stereo_slow_fast(name, golden):
 
 
 @torch.no_grad()
-def test_raft_graph_follows_weight_and_backend_changes():
+@pytest.mark.parametrize("c8_loop", [False, True])
+def test_raft_graph_follows_weight_and_backend_changes(c8_loop):
     """A captured iteration holds pointers to packed weights: load_state_dict / in-place updates /
-    set_backend after the first forward must give the result of a fresh model, not a stale replay."""
+    set_backend after the first forward must give the result of a fresh model, not a stale replay.
+    c8_loop: the default loop (loop_c8: its captured units live in the loop object; the fresh model replays its own capture,
+    which is the same arithmetic); else the round-2 loop, whose capture equals the plain loop bit for bit."""
     from dkt_stereo_amd import conv
     model, sd = _raft()
+    model.use_c8 = c8_loop
+
+    def captured(m):
+        st = m._graph_state
+        g = (st["c8"].graph if st.get("c8") is not None else None) if c8_loop else st["graph"]
+        return g
+
     i1, i2 = _synth.image_pair(0, 1, 64, 128, 12)
     a = model(G(i1), G(i2), iters=6, test_mode=True)[1]
-    graph = model._graph_state["graph"]
-    assert graph is not None
+    graph = captured(model)
+    assert graph
     sd2 = {k: (v * 1.02 if k.startswith("update_block.") and v.dtype.is_floating_point else v) for k, v in sd.items()}
     model.load_state_dict(sd2)
     b = model(G(i1), G(i2), iters=6, test_mode=True)[1]
-    assert model._graph_state["graph"] is not graph
+    assert captured(model) is not graph
     fresh, _ = _raft()
     fresh.load_state_dict(sd2)
-    fresh.use_hip_graph = False
+    fresh.use_c8 = c8_loop
+    fresh.use_hip_graph = c8_loop
     want = fresh(G(i1), G(i2), iters=6, test_mode=True)[1]
     assert torch.equal(b, want) and not torch.equal(a, b)
     # in-place parameter update (what an optimiser step does)
-    graph = model._graph_state["graph"]
+    graph = captured(model)
     model.update_block.flow_head.conv2.weight.mul_(0.5)
     fresh.update_block.flow_head.conv2.weight.mul_(0.5)
     assert torch.equal(model(G(i1), G(i2), iters=6, test_mode=True)[1], fresh(G(i1), G(i2), iters=6, test_mode=True)[1])
-    assert model._graph_state["graph"] is not graph
+    assert captured(model) is not graph
     # backend switch
     prev = conv.get_backend()
     try:
@@ -350,7 +361,10 @@ def test_two_threads_two_replicas_one_device():
     replica._modules = dict(model._modules)          # parameters' storage and (here) every __dict__ entry
     pairs = [_synth.image_pair(s, 1, 64, 128, sh) for s, sh in ((0, 12), (5, 20))]
     dev_pairs = [(G(a), G(b)) for a, b in pairs]
-    want = [model(a, b, iters=7, test_mode=True)[1].clone() for a, b in dev_pairs]
+    want = []
+    for a, b in dev_pairs:                           # a fresh state per pair, as each thread below has: the default loop picks
+        model._graph_state = None                    # its C8S activation scales from the first pair a state sees
+        want.append(model(a, b, iters=7, test_mode=True)[1].clone())
     model._graph_state = None
     torch.cuda.synchronize()
     for rounds in range(3):                          # three fresh rounds: the interleaving differs every time
