@@ -718,6 +718,11 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec 
     return dkt_launch_status();
 }
 
+#if !defined(CONV_TU_PASSES) || CONV_TU_PASSES == 3
+#include "conv_ws.h"      // weights-stationary kernel of the 64 -> 64 layers (three-pass form only)
+#define CONV_HAVE_WS 1
+#endif
+
 // Tile shape by layer width and image size.  Wide layers put all four waves on the
 // channel axis (one block = up to 256 channels: each patch is staged once); narrow
 // layers put them on rows.  Images too small to give every CU a block with 4-row
@@ -725,6 +730,11 @@ static int launch_conv(ConvArgs a, int B, hipStream_t st, const ConvSecond *sec 
 template <int KS, int PASSES>
 static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const ConvSecond *sec = nullptr) {
     const long tiles4 = (long)a.tiles_w * ((a.H + 3) / 4) * B;    // blocks if a block covers 4 rows
+#ifdef CONV_HAVE_WS
+    if constexpr (KS == 3 && PASSES == 3) {
+        if (!sec && conv_ws_eligible(a, B)) return launch_conv_ws(a, B, st);
+    }
+#endif
     if (a.in_norm) {
         // instance norm + ReLU of the input folded into the staging: the second 3x3 layer of the feature
         // encoder's residual blocks (core/extractor.py:46-50; 64, 96 and 128 channels) -- the same tile
