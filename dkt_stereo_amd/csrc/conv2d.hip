@@ -789,6 +789,12 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const Con
 // 2-row output tiles keep the (2*TR+1) x 65 input patch at 52 KB per LDS stage.
 template <int KS, int PASSES>
 static int launch_conv_stride2(const ConvArgs &a, int B, hipStream_t st) {
+    if constexpr (KS == 3 && PASSES == 3) {
+        // 128 co x 4 rows with 16-channel chunks (9 x 65 patch, 56 KB per stage, one block per CU): twice the MFMAs per weight
+        // fragment of the 2-row form -- 64->96 @736x1248 281 -> 243 us, two images 518 -> 422; 96->128 @368x624 x 2: 174 -> 138
+        if (a.Cout <= 128 && (long)a.tiles_w * ((a.Ho + 3) / 4) * B >= 512)
+            return launch_conv<KS, 2, 2, 2, PASSES, 2, 2, 1>(a, B, st);
+    }
     if (a.Cout <= 128) return launch_conv<KS, 2, 2, 1, PASSES, 2, 2>(a, B, st);   // 128 co x 2 rows
     return launch_conv<KS, 4, 1, 1, PASSES, 2, 2>(a, B, st);                      // 256 co x 1 row
 }
@@ -804,6 +810,7 @@ template <int PASSES>
 static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) {
     if (stride == 2) {
         if (sec || a.in_norm) return DKT_E_UNSUPPORTED;
+
         if (KH == 3) return launch_conv_stride2<3, PASSES>(a, B, st);
         return launch_conv_stride2<1, PASSES>(a, B, st);
     }

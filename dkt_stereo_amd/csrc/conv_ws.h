@@ -39,28 +39,6 @@ __device__ __forceinline__ unsigned ws_bits(ws_h2 h) {
     return v.u;
 }
 
-#ifndef WS_A_ACC
-#define WS_A_ACC 48   // weight fragments (of 72) kept in acc VGPRs
-#endif
-#ifndef WS_BUF
-#define WS_BUF 1
-#endif
-#ifndef WS_PK
-#define WS_PK 1
-#endif
-#ifndef WS_LATE
-#define WS_LATE 1
-#endif
-#ifndef WS_RB
-#define WS_RB 4
-#endif
-#ifndef WS_HOIST
-#define WS_HOIST 0
-#endif
-#ifndef WS_ABL
-#define WS_ABL 0      // timing-only builds (tools/_build): 1 no epilogue, 2 no staging, 4 no fragment reads
-#endif
-
 template <int NRM, int EPI>
 __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
     constexpr int KS = 3, HALO = 1;
@@ -73,7 +51,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
     constexpr int NCH = 4;                   // 16-channel chunks of the 64 input channels
     constexpr int NSTEP = 3 * (NF + 2);      // (dx, patch row) steps per chunk
     constexpr int NG = 16;                   // issue groups per chunk (conv_ws_group_first)
-    constexpr int RB = WS_RB;                    // B-fragment ring: reads run two steps ahead
+    constexpr int RB = 4;                    // B-fragment ring: reads run two groups ahead
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 2 * STAGE words (+ 8 dummy)
 
     const int tid = threadIdx.x;
@@ -110,12 +88,12 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
                 Ahi[c * 9 + tap] = *(const f16x8 *)(a.whi + off);
                 Alo[c * 9 + tap] = *(const f16x8 *)(a.wlo + off);
             }
-        // register classes by hand: accumulators (64) + WS_A_ACC fragments (4 registers each) fill the 256 acc VGPRs, the other
+        // register classes by hand: accumulators (64) + 48 of the 72 fragments (4 registers each) fill the 256 acc VGPRs, the other
         // fragments stay in arch VGPRs beside everything the VALU touches (left to itself the allocator shuffles fragments
         // between the two files inside the loop and spills)
 #pragma unroll
-        for (int i = 0; i < (WS_A_ACC >= 0 ? NCH * 9 : 0); ++i) {
-            if (i < WS_A_ACC / 2) {
+        for (int i = 0; i < NCH * 9; ++i) {
+            if (i < 24) {
                 asm volatile("" : "+a"(Ahi[i]));
                 asm volatile("" : "+a"(Alo[i]));
             } else {
@@ -136,7 +114,6 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
     float sscale[SIT];                       // in_scale inside the image, 0 outside (the zero padding)
     float sreg[SIT][8];
     unsigned shw[SIT][4], slw[SIT][4];
-    const float *sbase_ = nullptr;
     __amdgpu_buffer_rsrc_t srsrc;            // the 8 planes this wave stages (wave-uniform descriptor: no 64-bit address math)
     const unsigned plane_bytes = (unsigned)HW * 4u;
     float nmean[NRM ? 8 : 1], ninv[NRM ? 8 : 1];
@@ -156,10 +133,11 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
         const float *sbase = a.src[0] + (long)tb * a.src_bs[0] + (long)cb * HW;
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)sbase);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)sbase >> 32));
-        sbase_ = sbase;
         srsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((size_t)hi32 << 32) | lo32), 0, (int)(8u * plane_bytes), 0x00020000);
         if (NRM) {
-            const float *np = a.in_norm + 2 * ((long)tb * 64 + cb);
+            // (mean, 1/std) of the 8 planes from the block's LDS copy: wave-uniform LDS reads instead of global loads, which
+            // would sit in the in-order memory counter in front of the chunk's activation requests
+            const float *np = (const float *)(lds + 2 * STAGE + 8) + 2 * (tb * 64 + cb);
 #pragma unroll
             for (int j = 0; j < (NRM ? 8 : 1); ++j) {
                 nmean[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(np[2 * j])));
@@ -175,11 +153,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * q + jj;
-#if WS_BUF
                 sreg[it][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srsrc, spix[it], j * plane_bytes, 0));
-#else
-                sreg[it][j] = *(const float *)((const char *)(sbase_ + (long)j * HW) + spix[it]);
-#endif
             }
         }
     };
@@ -195,19 +169,12 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
             }
             // (finite values only: a NaN / Inf at a clamped address would reach the padding through 0 * x; check_finite
             // rejects such inputs anyway).  Packed conversions: v_cvt_pk_f16_f32, the split of conv2d_f16s_kernel bit for bit
-#if WS_PK
             const ws_f2 xv = {u0 * sscale[it], u1 * sscale[it]};
             const ws_h2 hv = __builtin_convertvector(xv, ws_h2);
             const ws_f2 rv = {xv[0] - (float)hv[0], xv[1] - (float)hv[1]};
             const ws_h2 lv = __builtin_convertvector(rv, ws_h2);
             shw[it][q] = ws_bits(hv);
             slw[it][q] = ws_bits(lv);
-#else
-            const float x0 = u0 * sscale[it], x1 = u1 * sscale[it];
-            const _Float16 h0_ = (_Float16)x0, h1_ = (_Float16)x1;
-            shw[it][q] = pack_h2(h0_, h1_);
-            slw[it][q] = pack_h2((_Float16)(x0 - (float)h0_), (_Float16)(x1 - (float)h1_));
-#endif
             if (q == 3) {
                 const int pp = lane + 64 * (it * PG + spgrp);
                 unsigned *dst = pp < NPP ? buf + pp * PITCH + 4 * swave : lds + 2 * STAGE;   // surplus lanes -> dummy
@@ -379,16 +346,19 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
         }
     };
 
-    // ---- main stream.  Per step: the fragment reads of step s + 2, one or two staging slices of the NEXT chunk (fp32 loads
-    // in steps 0..5, convert + LDS writes in steps 6..17), then the step's 3 / 6 / 9 MFMAs.
+    // ---- main stream.  A chunk's 18 (dx, patch row) units are issued as 16 groups; a group carries the fragment reads of the
+    // group after next, its share of the NEXT chunk's staging (fp32 requests in groups 0..5, convert + LDS writes in groups
+    // 9..15: a request has ~60 MFMAs to come back) and its 3 / 6 / 9 MFMAs.
+    if (NRM) {
+        // every image's 64 x (mean, 1/std) behind the two stages (launch_conv_ws sizes the allocation: B * 512 bytes)
+        float *np = (float *)(lds + 2 * STAGE + 8);
+        for (int i = tid; i < a.n_co * 128; i += 256) np[i] = a.in_norm[i];
+        __syncthreads();
+    }
     stage_tile(h0, w0);
     stage_select(b, 0);
     stage_load(0, NSL);
     stage_store(lds, 0, NSL);
-    if (WS_HOIST) {
-        stage_select(b, 1);
-        stage_load(0, NSL);
-    }
     __builtin_amdgcn_sched_barrier(0);        // the prologue's staging registers are free before the 288 weight registers fill
     load_weights();
     __syncthreads();
@@ -404,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
             const unsigned *cur = lds + (c & 1) * STAGE;
             unsigned *nxt = lds + ((c + 1) & 1) * STAGE;
             if (c + 1 < NCH) {
-                if (c != 0 || !WS_HOIST) stage_select(b, c + 1);
+                stage_select(b, c + 1);
             } else {
                 // the next tile's first chunk; the block's very last chunk stages its own tile's chunk 0 again, harmlessly
                 stage_select(nb, 0);
@@ -413,17 +383,15 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 // fragment reads run two groups ahead
-                if (!(WS_ABL & 4) && g + 2 < NG) {
+                if (g + 2 < NG) {
 #pragma unroll
                     for (int u = conv_ws_group_first(g + 2); u < conv_ws_group_first(g + 2) + conv_ws_group_units(g + 2); ++u)
                         loadB(u % RB, cur, u);
                 }
-                if (!(WS_ABL & 2)) {
-                    if (g < 6) stage_load(2 * g, 2 * g + 2);                                   // slices 2g, 2g + 1
-                    else if (g == 9) stage_store(nxt, 0, 1);
-                    else if (g >= 10 && g < 15) stage_store(nxt, 2 * (g - 10) + 1, 2 * (g - 10) + 3);
-                    else if (g == 15) stage_store(nxt, 11, 12);
-                }
+                if (g < 6) stage_load(2 * g, 2 * g + 2);                                   // slices 2g, 2g + 1
+                else if (g == 9) stage_store(nxt, 0, 1);
+                else if (g >= 10 && g < 15) stage_store(nxt, 2 * (g - 10) + 1, 2 * (g - 10) + 3);
+                else if (g == 15) stage_store(nxt, 11, 12);
                 mma_group(c, g);
                 if (conv_ws_group_units(g) == 1 && conv_ws_rows_fed(conv_ws_group_first(g) % (NF + 2), NF) == 1) {
                     // three MFMAs on ONE accumulator: adjacent (an issue slot between two dependent MFMAs costs ~40 cycles)
@@ -447,13 +415,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
             loadB(0, nxt, 0);
             loadB(1, nxt, 1);
         }
-        // the wave's memory counter is in order: a load issued behind the epilogue's stores is not back before they have
-        // reached memory, so the next tile's second chunk is requested first
-        if (WS_HOIST && !(WS_ABL & 2) && have_next) {
-            stage_select(nb, 1);
-            stage_load(0, NSL);
-        }
-        if (!(WS_ABL & 8)) { if (!(WS_ABL & 1) || !have_next) epilogue(); }
+        epilogue();
         if (!have_next) break;
         tile = tn; h0 = nh0; w0 = nw0; b = nb;
         zero_acc();
@@ -463,26 +425,22 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
 // 64 -> 64, 3x3, stride 1, one 64-channel source, epilogues 0 / 3: images with at least two tiles per CU take the
 // weights-stationary kernel (DKT_CONV_WS=0 keeps the streaming kernel: A/B and bit-identity tests of the round-2 path)
 static bool conv_ws_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("DKT_CONV_WS");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
+    const char *e = getenv("DKT_CONV_WS");      // read per launch: the tests compare both kernels in one process
+    return !(e && e[0] == '0');
 }
 
 static bool conv_ws_eligible(const ConvArgs &a, int B) {
     if (!conv_ws_enabled()) return false;
     if (a.nsrc != 1 || a.src_ch[0] != 64 || a.Cout != 64 || a.nch16 != 4 || a.CoutPad != 64) return false;
     if (a.epi != 0 && a.epi != 3) return false;
-    if (a.Ho != a.H || a.Wo != a.W) return false;
+    if (a.Ho != a.H || a.Wo != a.W || B > 64) return false;
     const long tiles = (long)a.tiles_w * ((a.H + 7) / 8) * B;
     return tiles >= 512;
 }
 
 static int launch_conv_ws(ConvArgs a, int B, hipStream_t st) {
     constexpr int STAGE = 10 * 34 * 12 * 2;
-    const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned);
+    const size_t lds = ((size_t)2 * STAGE + 8) * sizeof(unsigned) + (a.in_norm ? (size_t)B * 512 : 0);
     static int ready[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -494,7 +452,7 @@ static int launch_conv_ws(ConvArgs a, int B, hipStream_t st) {
         const void *all[6] = {(const void *)conv64_ws_kernel<0, 0>, (const void *)conv64_ws_kernel<0, 1>, (const void *)conv64_ws_kernel<0, 3>,
                               (const void *)conv64_ws_kernel<1, 0>, (const void *)conv64_ws_kernel<1, 1>, (const void *)conv64_ws_kernel<1, 3>};
         for (int i = 0; i < 6; ++i) {
-            hipError_t e = hipFuncSetAttribute(all[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(all[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)2 * STAGE + 8) * sizeof(unsigned)) + 64 * 512);
             if (e != hipSuccess) return (int)e;
         }
         int cus = 0;
@@ -502,7 +460,7 @@ static int launch_conv_ws(ConvArgs a, int B, hipStream_t st) {
         ready[dev & 63] = cus;
     }
     a.tiles_xy = a.tiles_w * ((a.H + 7) / 8);
-    a.n_co = 1;
+    a.n_co = B;                       // (the kernel has one channel block; the field carries the batch size for the in_norm copy)
     const long total = (long)a.tiles_xy * B;
     if (total > 0x7fffffffL) return DKT_E_SHAPE;
     a.total_tiles = (int)total;

@@ -381,3 +381,77 @@ def test_paired_context_heads_equal_the_single_launches():
     for g, w in zip(got, want):
         for u, v in zip(g, w):
             assert torch.equal(u, v)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Weights-stationary 64 -> 64 convolution of the encoders' full-resolution layers (csrc/conv_ws.h; core/extractor.py:122-143,
+# 46-60): against fp64 and against the streaming kernel it replaces (same split, another summation order), every epilogue the
+# encoders use, partial tiles, several images per launch, launch-to-launch reproducibility.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ws_forms(B, H, W, seed):
+    import torch.nn as nn
+    from dkt_stereo_amd import conv
+    from dkt_stereo_amd.extractor import instance_norm_params
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    torch.manual_seed(seed)                 # the layer's initialisation
+    layer = nn.Conv2d(64, 64, 3, padding=1).to(DEV)
+    x = torch.randn(B, 64, H, W, device=DEV, generator=g) * 3.0 + 0.5
+    res = torch.randn(B, 64, H, W, device=DEV, generator=g).relu()
+    p = instance_norm_params(nn.InstanceNorm2d(64), x)
+    out = {}
+    with torch.no_grad():
+        out["relu"] = conv.conv2d(x, layer, relu=True)
+        out["join"] = conv.conv2d_fused(x, layer, relu=True, residual=res)
+        y, st = conv.conv2d_stats(x, layer, in_norm=p)
+        out["in_norm"] = y
+        out["params"] = instance_norm_params(nn.InstanceNorm2d(64), y, st)
+        y, st = conv.conv2d_stats(x, layer)
+        out["plain_stats"] = y
+        out["plain_params"] = instance_norm_params(nn.InstanceNorm2d(64), y, st)
+        out["in_norm_join"] = conv.conv2d_fused(x, layer, relu=False, residual=res, in_norm=p)
+    return layer, x, res, out
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 264, 544),      # 561 tiles: every block two or three
+                                   (3, 130, 333),      # partial tiles on both axes, three images (per-image norm parameters)
+                                   (2, 736, 1248)])    # the benchmark's feature-encoder launch
+def test_weights_stationary_conv_matches_fp64_and_the_streaming_kernel(B, H, W, monkeypatch):
+    monkeypatch.setenv("DKT_CONV_WS", "1")
+    layer, x, res, ws = _ws_forms(B, H, W, 7)
+    monkeypatch.setenv("DKT_CONV_WS", "0")
+    _, _, _, st = _ws_forms(B, H, W, 7)
+    w, b = layer.weight.detach().double(), layer.bias.detach().double()
+    ref = F.conv2d(x.double(), w, b, padding=1)
+    xn = F.instance_norm(x.double()).relu()
+    refn = F.conv2d(xn, w, b, padding=1)
+    want = {"relu": ref.relu(), "join": (res.double() + ref.relu()).relu(), "in_norm": refn, "plain_stats": ref,
+            "in_norm_join": (res.double() + refn).relu()}
+    for k, r in want.items():
+        assert _rel(ws[k], r) < 2.5e-6, k                   # the split-fp16 class (tests/test_gpu_conv.py's bound)
+        assert _rel(ws[k], st[k].double()) < 2.5e-6, k       # the kernel it replaces
+    for k in ("params", "plain_params"):                     # (mean, 1/std) from the epilogue's partial sums
+        assert _rel(ws[k], st[k].double()) < 4e-6, k
+    mean = refn.mean(dim=(2, 3)).reshape(-1)
+    istd = (refn.var(dim=(2, 3), unbiased=False) + 1e-5).rsqrt().reshape(-1)
+    assert _rel(ws["params"][:, 0], mean) < 4e-6 and _rel(ws["params"][:, 1], istd) < 4e-6
+
+
+def test_weights_stationary_conv_is_reproducible_and_gated(monkeypatch):
+    import torch.nn as nn
+    from dkt_stereo_amd import conv
+    monkeypatch.setenv("DKT_CONV_WS", "1")
+    _, _, _, a = _ws_forms(2, 300, 500, 11)
+    _, _, _, b = _ws_forms(2, 300, 500, 11)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # images below two tiles per CU, other widths and strides stay on the streaming kernel: same bits with the switch on or off
+    torch.manual_seed(3)
+    for cin, cout, H, W, stride in ((64, 64, 96, 160, 1), (64, 96, 264, 544, 1), (64, 64, 264, 544, 2)):
+        layer = nn.Conv2d(cin, cout, 3, padding=1, stride=stride).to(DEV)
+        x = torch.randn(1, cin, H, W, device=DEV)
+        with torch.no_grad():
+            monkeypatch.setenv("DKT_CONV_WS", "1")
+            y1 = conv.conv2d(x, layer, relu=True)
+            monkeypatch.setenv("DKT_CONV_WS", "0")
+            y0 = conv.conv2d(x, layer, relu=True)
+        assert torch.equal(y0, y1), (cin, cout, H, W, stride)
