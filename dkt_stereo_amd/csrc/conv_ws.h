@@ -9,15 +9,17 @@
 // products.  So:
 //   * block = 4 waves, ONE wave per SIMD, the whole 512-register file (arch + acc VGPRs) per wave: 288 weight registers loaded
 //     once per launch, 64 accumulators (32 co x 4 rows x 32 columns), the rest staging / fragments;
-//   * wave (wm, wn): wm = 32-channel half, wn = row half of the block's 8 rows x 32 columns output tile; blocks are persistent;
-//   * the only operand stream is the activation patch: fp32 NCHW -> registers -> [instance norm + ReLU of the producer]
-//     -> (hi, lo) fp16 -> LDS as [pixel][16 channels] (conv2d_f16s_kernel's staging and arithmetic, so results are
-//     bit-identical to that kernel), double-buffered per 16-channel chunk, one barrier per chunk of 108 MFMAs per wave;
+//   * wave (wm, wn): wm = 32-channel half, wn = row half of the block's 8 rows x 32 columns output tile; blocks are persistent,
+//     tiles in an XCD-aware column-major order;
+//   * the only operand stream is the activation patch: fp32 NCHW -> registers (buffer loads: the channel offset is a scalar)
+//     -> [instance norm + ReLU of the producer] -> (hi, lo) fp16 (conv2d_f16s_kernel's split, bit for bit) -> LDS as
+//     [pixel][16 channels], double-buffered per 16-channel chunk, one barrier per chunk of 108 MFMAs per wave;
 //   * taps walk column by column: a B fragment (one patch row at one dx) feeds the three dy that use it -- 36 fragment-pair
 //     reads per 108 MFMAs; no weight traffic at all inside the loop.
-// Same packed weight image, argument block, epilogues (bias / ReLU / output statistics / residual join) and summation order
-// per accumulator as the streaming kernel (chunk-major, then dx-major instead of dy-major taps: NOT bit-identical to it,
-// the same error bound; tests compare both against fp64).
+// Same packed weight image, argument block and epilogue contracts (bias / ReLU / output statistics / residual join) as the
+// streaming kernel; the summation order per accumulator differs (chunk-major, then dx-major instead of dy-major taps), so the
+// results are NOT bit-identical to it -- the same error bound against fp64 (tests/test_gpu_round4.py compares both).
+// Measurements and what was tried: DESIGN.md 3.6b.
 
 // (dx, patch row) units of a chunk are issued in 16 groups: single units, except that the last row of a column of taps
 // (3 MFMAs on the last accumulator) shares a group with the first row of the next column (3 MFMAs on accumulator 0)

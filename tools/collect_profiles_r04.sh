@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round 3 evidence on a GPU box -> gpurun_out/ (copy what is to be kept into profiles/):  bash tools/collect_profiles_r04.sh [steps...]
-# steps: tests prof bench micro trace stress stages pmc gwc   (default: all)
+# steps: tests prof bench micro trace stress stages pmc ws gwc   (default: all but gwc)
 R=r04
 O=gpurun_out
-STEPS=${@:-tests prof bench micro trace stress stages pmc}
+STEPS=${@:-tests prof bench micro trace stress stages pmc ws}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && export PYTHONPATH=$GRAFT_REPO_ROOT
 for s in $STEPS; do case $s in
 tests) python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/${R}_gputests.txt ;;
@@ -25,6 +25,7 @@ trace) python tools/gru_c8_trace.py --rebuild 2>&1 | grep -v amdgpu > $O/${R}_gr
 stress) python tools/stress_forward.py 200 2>&1 | grep -v amdgpu > $O/${R}_stress_forward.txt ;;
 stages) python tools/iteration_stages.py 2>&1 | grep -v amdgpu > $O/${R}_iteration_stages.txt ;;
 pmc) bash tools/pmc/run_pmc_r04.sh > $O/${R}_pmc.log 2>&1; python tools/pmc/make_traffic_r04.py $O/r04_pmc --profiles >> $O/${R}_pmc.log 2>&1 ;;
+ws) (python tools/conv_ws_check.py --time; DKT_CONV_WS=0 python tools/conv_ws_check.py --time) 2>&1 | grep -v amdgpu > $O/${R}_conv_ws.txt ;;
 gwc) bash tools/gwc_pmc.sh > /dev/null 2>&1 ;;
 esac; done
 ls -la $O | tail -20
