@@ -252,6 +252,9 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
     // stats_ws contract, entry = (tile, wn)); 3: residual join out = relu(e_c0 + [relu](v)) (core/extractor.py:60 with the norm
     // folded into the weights).  Stores / residual loads go through buffer descriptors: the channel offset is a scalar, the
     // pixel offset one VGPR per row -- no 64-bit address arithmetic; a scheduling fence per row keeps one row's values live.
+    // (Measured and not kept: the values transposed through a wave-private LDS area and stored / the residual fetched as 16-byte
+    // accesses -- 16 instead of 64 per wave and tile: epilogue 6 550 against 4 810 cycles, the LDS round trip costs more than the
+    // narrower store stream.)
     auto wave_rsrc = [&](const float *base) {
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)base);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)((size_t)base >> 32));
@@ -269,31 +272,39 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
             return ok ? (unsigned)(4 * kg) * plane_bytes + (unsigned)(oh * a.W + ow) * 4u : 0x80000000u;   // outside: dropped
         };
         if (EPI == 3) {
-            // (in-order memory counter: row n + 1's residual values are requested before row n's stores)
+            // The wave's memory counter is in order: a residual request issued behind a row's stores is not back before those
+            // stores have reached memory (requests one row ahead measured ~2 500 cycles of waiting per row).  Rows 0 and 1 are
+            // requested up front; row n + 2 is requested once row n's results are computed (its registers are free) and BEFORE
+            // row n's stores are issued.  (All four rows up front need 64 registers: the allocator spills weights for them.)
             const auto crsrc = wave_rsrc(a.e_c0 + (long)b * a.e_c0_bs + (long)(wm * 32) * HW);
             float gc[2][16];
-            bool ok;
-            unsigned vo = row_off(0, ok);
+            unsigned vo[NF];
+            auto request = [&](int n) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                gc[0][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, vo, ((r & 3) + 8 * (r >> 2)) * plane_bytes, 0));
+                for (int r = 0; r < 16; ++r)
+                    gc[n & 1][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, vo[n], ((r & 3) + 8 * (r >> 2)) * plane_bytes, 0));
+            };
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
-                unsigned vn = 0;
-                if (n + 1 < NF) {
-                    bool okn;
-                    vn = row_off(n + 1, okn);
+                bool ok;
+                vo[n] = row_off(n, ok);
+            }
+            request(0);
+            request(1);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        gc[(n + 1) & 1][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, vn, ((r & 3) + 8 * (r >> 2)) * plane_bytes, 0));
-                }
+            for (int n = 0; n < NF; ++n) {
+                float o[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[n][r] * a.out_scale + bv[r];
-                    const float o = dkt_relu(__fadd_rn(gc[n & 1][r], a.relu ? dkt_relu(v) : v));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), orsrc, vo, ((r & 3) + 8 * (r >> 2)) * plane_bytes, 0);
+                    o[r] = dkt_relu(__fadd_rn(gc[n & 1][r], a.relu ? dkt_relu(v) : v));
                 }
-                vo = vn;
+                __builtin_amdgcn_sched_barrier(0);
+                if (n + 2 < NF) request(n + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), orsrc, vo[n], ((r & 3) + 8 * (r >> 2)) * plane_bytes, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             return;
@@ -371,6 +382,7 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
         const bool have_next = tn < a.total_tiles;
         int nh0 = h0, nw0 = w0, nb = b;
         if (have_next) decode(tn, nh0, nw0, nb);
+        // @trace(0)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const unsigned *cur = lds + (c & 1) * STAGE;
@@ -414,12 +426,18 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
-            loadB(0, nxt, 0);
-            loadB(1, nxt, 1);
+            // @trace(1 + c)
+            if (c + 1 < NCH) {           // (the next tile's first fragments are read behind the epilogue: 16 registers it needs)
+                loadB(0, nxt, 0);
+                loadB(1, nxt, 1);
+            }
         }
         epilogue();
+        // @trace(5)
         if (!have_next) break;
         tile = tn; h0 = nh0; w0 = nw0; b = nb;
+        loadB(0, lds, 0);
+        loadB(1, lds, 1);
         zero_acc();
     }
 }

@@ -6,7 +6,7 @@ cd $D
 /opt/rocm/lib/llvm/bin/llvm-objdump --offloading tu3.o >/dev/null 2>&1
 f=$(ls | grep gfx950 | head -1)
 /opt/rocm/lib/llvm/bin/llvm-objdump -d $f > all.s
-awk '/^[0-9a-f]+ <_Z16conv64_ws_kernelILi0ELi0EEv8ConvArgs>:/{p=1} /^[0-9a-f]+ <_Z16conv64_ws_kernelILi0ELi1/{p=0} p' all.s > ws0.s
+awk '/^[0-9a-f]+ <_Z16conv64_ws_kernelILi0ELi3EEv8ConvArgs>:/{p=1} /^[0-9a-f]+ <_Z16conv64_ws_kernelILi1ELi0/{p=0} p' all.s > ws0.s
 wc -l ws0.s
 a=$(grep -n v_mfma ws0.s | head -1 | cut -d: -f1); b=$(grep -n v_mfma ws0.s | tail -1 | cut -d: -f1); echo "hot loop lines $a $b"
 sed -n "${a},${b}p" ws0.s | awk '{print $1}' | sort | uniq -c | sort -rn | head -${2:-30}
