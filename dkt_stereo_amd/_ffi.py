@@ -156,7 +156,6 @@ SIGNATURES = {
     "dkt_conv2d_stem7_packed_elems": [_i],
     "dkt_conv2d_stem7_pack": [_vp, _i, _i, _f, _vp, _vp, _i, _vp],
     "dkt_conv2d_stem7": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "dkt_conv2d_stem7_stats": [_vp, _l, _vp, _vp, _vp, _f, _f, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_f16s_strided": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _f, _vp, _l,
                                 _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dkt_conv2d_f16s_gate_zr": [_pp, _ip, _lp, _i, _vp, _vp, _vp, _f, _f, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l,

@@ -296,9 +296,8 @@ def conv2d_accumulate(x, layer, out, diff=None):
     return out
 
 
-def _conv2d_stem7(x, layer, relu, out, stats=False):
-    """7x7 stem (Cin <= 4) on the matrix cores (dkt_conv2d_stem7); packed weights cached on the layer.  stats: also the
-    instance-norm statistics of the result (dkt_conv2d_stem7_stats) -> (out, OutStats)."""
+def _conv2d_stem7(x, layer, relu, out):
+    """7x7 stem (Cin <= 4) on the matrix cores (dkt_conv2d_stem7); packed weights cached on the layer."""
     _ffi.require_gpu(x)
     _ffi.require_no_grad(x)
     if not _dense(x):
@@ -314,15 +313,6 @@ def _conv2d_stem7(x, layer, relu, out, stats=False):
     in_scale = 2.0 ** in_exp_of(layer)
     if out is None:
         out = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
-    if stats:
-        ws = torch.empty(int(L.dkt_conv2d_stats_ws_floats(B, cout, H, W)), device=x.device, dtype=torch.float32)
-        part = torch.empty(int(L.dkt_instance_norm_workspace(B * cout, H * W)), device=x.device, dtype=torch.uint8)
-        rc = L.dkt_conv2d_stem7_stats(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
-                                      None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale / in_scale, in_scale,
-                                      out.data_ptr(), out.stride(0), ws.data_ptr(), part.data_ptr(),
-                                      B, cin, cout, H, W, int(bool(relu)), _ffi.device_of(x), _ffi.stream_of(x))
-        _ffi.check(rc, "dkt_conv2d_stem7_stats")
-        return out, OutStats(part, B * cout, H * W)
     rc = L.dkt_conv2d_stem7(x.data_ptr(), x.stride(0), pk.hi.data_ptr(), pk.lo.data_ptr(),
                             None if pk.bias is None else pk.bias.data_ptr(), pk.inv_scale / in_scale, in_scale,
                             out.data_ptr(), out.stride(0), B, cin, cout, H, W, int(bool(relu)),
@@ -452,16 +442,12 @@ class OutStats:
 def stats_eligible(layer):
     """`layer` can accumulate its output's instance-norm statistics in the epilogue (dkt_conv_desc.stats_ws): the split-fp16
     kernel's plain epilogue, stride 1 or 2."""
-    if direct_eligible(layer):
-        return layer.weight.shape[0] <= 64           # the 7x7 stems: one 64-channel block per tile (dkt_conv2d_stem7_stats)
-    return hip_eligible(layer) and _stride_of(layer) in ((1, 1), (2, 2)) and not few_eligible(layer)
+    return hip_eligible(layer) and _stride_of(layer) in ((1, 1), (2, 2)) and not direct_eligible(layer) and not few_eligible(layer)
 
 
 def conv2d_stats(x, layer, in_norm=None):
     """conv(x) + bias with the statistics of its OWN output for the InstanceNorm2d that follows it
     (core/extractor.py:46-50): returns (out, OutStats).  `in_norm` as in conv2d_fused (stride 1 only)."""
-    if direct_eligible(layer) and in_norm is None and not isinstance(x, (list, tuple)):
-        return _conv2d_stem7(x, layer, False, None, stats=True)
     op = _Operands(x, layer)
     stride = _stride_of(layer)[0]
     Ho, Wo = (op.H - 1) // stride + 1, (op.W - 1) // stride + 1

@@ -791,7 +791,6 @@ extern "C" int dkt_motion_front_c8(const dkt_motion_front_desc *d, int device, v
     s.relu = 1;
     s.y_c8 = (char *)d->flo_c8; s.y_c8_bs = d->flo_c8_bstride_bytes; s.y_c8_plane = (long)Hp * Wp * 16; s.y_c8_Wp = Wp;
     s.y_c8_ch0 = d->flo_c8_ch0; s.act_scale = d->flo_act_scale;
-    s.stats_ws = nullptr;
     f.planes = d->planes; f.planes_bs = d->planes_bstride; f.n_co = d->n_co;
     f.head_bias = d->head_bias;
     f.x_old = d->x_old; f.x_old_bs = d->x_old_bstride;

@@ -58,13 +58,10 @@ extern "C" int dkt_conv2d_stem7_pack(const float *w, int Cout, int Cin, float sc
     return dkt_launch_status();
 }
 
-int conv_stats_reduce(const float *ws, double *part, int B, int C, long entries, long HW, hipStream_t st);      // norm.hip
-
 static int stem7_impl(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
                       const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
                       void *y_c8, long y_c8_bstride_bytes, int y_c8_ch0, float act_scale,
-                      int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream,
-                      float *stats_ws = nullptr, void *stats_part = nullptr) {
+                      int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream) {
     if (!x || !w_hi || !w_lo || (!y && !y_c8)) return DKT_E_NULL;
     if (B <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || H <= 0 || W <= 0 || B > 65535) return DKT_E_SHAPE;
     if (!(in_scale > 0.0f) || !(out_scale > 0.0f) || !(act_scale > 0.0f) || (y_c8_ch0 & 7)) return DKT_E_SHAPE;
@@ -83,17 +80,11 @@ static int stem7_impl(const float *x, long x_bstride, const void *w_hi, const vo
     dkt_act_c8_dims(H, W, &Hp, &Wp);
     a.y_c8 = (char *)y_c8; a.y_c8_bs = y_c8_bstride_bytes; a.y_c8_plane = (long)Hp * Wp * 16; a.y_c8_Wp = Wp; a.y_c8_ch0 = y_c8_ch0;
     a.act_scale = act_scale;
-    a.stats_ws = stats_ws;
-    if ((stats_ws != nullptr) != (stats_part != nullptr)) return DKT_E_NULL;
-    if (stats_ws && a.n_co != 1) return DKT_E_UNSUPPORTED;           // entries are per spatial tile: one channel block
     const long blocks = (long)a.tiles_xy * a.n_co;
     if (blocks > 0x7fffffffL) return DKT_E_SHAPE;
     DKT_ENTER(device);
     hipLaunchKernelGGL(conv2d_stem7_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
-    int rc = dkt_launch_status();
-    if (rc == DKT_OK && stats_ws)
-        rc = conv_stats_reduce(stats_ws, (double *)stats_part, B, Cout, (long)a.tiles_xy * 4, (long)H * W, (hipStream_t)stream);
-    return rc;
+    return dkt_launch_status();
 }
 
 extern "C" int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
@@ -102,15 +93,6 @@ extern "C" int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi
     if (!y) return DKT_E_NULL;
     return stem7_impl(x, x_bstride, w_hi, w_lo, bias, out_scale, in_scale, y, y_bstride, nullptr, 0, 0, 1.0f,
                       B, Cin, Cout, H, W, relu, device, stream);
-}
-
-extern "C" int dkt_conv2d_stem7_stats(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
-                                      const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
-                                      float *stats_ws, void *stats_part,
-                                      int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream) {
-    if (!y || !stats_ws || !stats_part) return DKT_E_NULL;
-    return stem7_impl(x, x_bstride, w_hi, w_lo, bias, out_scale, in_scale, y, y_bstride, nullptr, 0, 0, 1.0f,
-                      B, Cin, Cout, H, W, relu, device, stream, stats_ws, stats_part);
 }
 
 extern "C" int dkt_conv2d_stem7_c8(const float *x, long x_bstride, const void *w_hi, const void *w_lo,

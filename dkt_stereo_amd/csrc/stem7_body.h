@@ -23,10 +23,6 @@ struct Stem7Args {
     long y_c8_bs, y_c8_plane;
     int y_c8_Wp, y_c8_ch0;
     float act_scale;
-    // optional instance-norm statistics of the values written (dkt_conv2d_stem7_stats): every wave stores the sums and sums of
-    // squares of its 64 channels over its 32 pixels to stats_ws[((b * tiles_xy * 4 + t * 4 + wave) * Cout + co) * 2 + {0, 1}]
-    // (conv2d.hip's stats_ws contract; conv_stats_reduce folds the entries)
-    float *stats_ws;
 };
 
 // block = 4 waves = 4 output rows x 32 columns x 64 output channels: spatial tile t, channel block cb, batch item b.
@@ -107,40 +103,6 @@ __device__ __forceinline__ void stem7_tile(const Stem7Args &a, int t, int cb, in
             if (a.relu) t = dkt_relu(t);
             v[r] = co < a.Cout ? t : 0.0f;
             if (yo && inside && co < a.Cout) yo[(long)co * HW] = v[r];
-        }
-        if (a.stats_ws) {
-            // reduce-scatter over the 32 pixel lanes of each half-wave (conv2d.hip's statistics epilogue for 16 values per
-            // lane: one add across the two 16-lane groups, then 15 exchanges per statistic): lane li & 15 ends with value li & 15
-            float s1[16], s2[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float u = inside ? v[r] : 0.0f;
-                s1[r] = u;
-                s2[r] = __fmul_rn(u, u);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s1[i] = __fadd_rn(s1[i], __shfl_xor(s1[i], 16, 32));
-                s2[i] = __fadd_rn(s2[i], __shfl_xor(s2[i], 16, 32));
-            }
-#pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) {
-                const bool up = (li & d) != 0;
-#pragma unroll
-                for (int j = 0; j < d; ++j) {
-                    const float k1 = up ? s1[j + d] : s1[j], g1 = up ? s1[j] : s1[j + d];
-                    const float k2 = up ? s2[j + d] : s2[j], g2 = up ? s2[j] : s2[j + d];
-                    s1[j] = __fadd_rn(k1, __shfl_xor(g1, d, 32));
-                    s2[j] = __fadd_rn(k2, __shfl_xor(g2, d, 32));
-                }
-            }
-            const int vi = li & 15;
-            const int co = co0 + m * 32 + 4 * kg + (vi & 3) + 8 * (vi >> 2);
-            if (li < 16 && co < a.Cout) {
-                float *p = a.stats_ws + ((((long)b * a.tiles_xy + t) * 4 + wave) * a.Cout + co) * 2;
-                p[0] = s1[0];
-                p[1] = s2[0];
-            }
         }
         if (a.y_c8) {
             // C8S: groups of 8 consecutive channels per 16 bytes -- pairs of the lane's 4-channel groups are completed

@@ -469,11 +469,7 @@ class _Trunk(nn.Module):
                 and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             # fnet: the stem's normalise + ReLU pass is folded into its two consumers (layer1.0.conv1's staging, the
             # residual operand of layer1.0's join)
-            if EPILOGUE_STATS and stats_eligible(self.conv1):
-                raw, st = conv2d_stats(x, self.conv1)             # (round 4) the stem leaves its own statistics too
-                x = LazyNorm(self.norm1, raw, relu=True, stats=st)
-            else:
-                x = LazyNorm(self.norm1, self.conv1(x), relu=True)
+            x = LazyNorm(self.norm1, self.conv1(x), relu=True)
         else:
             x = conv_norm_act(self.conv1, self.norm1, x, True)
         return self.layer3(self.layer2(self.layer1(x)))

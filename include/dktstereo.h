@@ -357,13 +357,6 @@ int dkt_conv2d_stem7_pack(const float *w, int Cout, int Cin, float scale, void *
 int dkt_conv2d_stem7(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
                      const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
                      int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream);
-/* The same stem with the instance-norm statistics of its OWN output accumulated in the epilogue (the feature encoder's
- * conv1 -> norm1, core/extractor.py:136-139,180-186): stats_ws (dkt_conv2d_stats_ws_floats(B, Cout, H, W) floats) and
- * stats_part (dkt_instance_norm_workspace(B * Cout, H * W) bytes) as dkt_conv_desc.stats_ws / stats_part; Cout <= 64. */
-int dkt_conv2d_stem7_stats(const float *x, long x_bstride, const void *w_hi, const void *w_lo,
-                           const float *bias, float out_scale, float in_scale, float *y, long y_bstride,
-                           float *stats_ws, void *stats_part,
-                           int B, int Cin, int Cout, int H, int W, int relu, int device, void *stream);
 
 /* Direct exact-fp32 convolution (stride 1, "same" padding) for the two extreme shapes of the
  * update block: 3x3 with Cout <= 4 (flow_head.conv2 / disp_head.conv2, core/update.py:10) and

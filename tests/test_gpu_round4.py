@@ -455,28 +455,3 @@ def test_weights_stationary_conv_is_reproducible_and_gated(monkeypatch):
             monkeypatch.setenv("DKT_CONV_WS", "0")
             y0 = conv.conv2d(x, layer, relu=True)
         assert torch.equal(y0, y1), (cin, cout, H, W, stride)
-
-
-def test_stem_statistics_in_the_epilogue_match_the_statistics_pass():
-    """The feature encoder's 7x7 stem leaves the statistics of its own output (dkt_conv2d_stem7_stats; core/extractor.py:
-    136-139 with norm_fn='instance'): same values as the plain stem, (mean, 1/std) as from dkt_instance_norm_stats."""
-    import torch.nn as nn
-    from dkt_stereo_amd import conv
-    from dkt_stereo_amd.extractor import instance_norm_params
-    torch.manual_seed(5)
-    for B, H, W in ((2, 97, 131), (1, 264, 544)):
-        layer = nn.Conv2d(3, 64, 7, padding=3).to(DEV)
-        x = torch.rand(B, 3, H, W, device=DEV) * 2 - 1
-        with torch.no_grad():
-            assert conv.stats_eligible(layer)
-            y0 = conv.conv2d(x, layer)
-            y1, st = conv.conv2d_stats(x, layer)
-            assert torch.equal(y0, y1)
-            norm = nn.InstanceNorm2d(64)
-            p_pass = instance_norm_params(norm, y0)
-            p_epi = instance_norm_params(norm, y1, st)
-            assert _rel(p_epi, p_pass) < 4e-6
-            ref = F.conv2d(x.double(), layer.weight.double(), layer.bias.double(), padding=3)
-            mean = ref.mean(dim=(2, 3)).reshape(-1)
-            istd = (ref.var(dim=(2, 3), unbiased=False) + 1e-5).rsqrt().reshape(-1)
-            assert _rel(p_epi[:, 0], mean) < 1e-5 and _rel(p_epi[:, 1], istd) < 1e-5
