@@ -444,7 +444,7 @@ def test_weights_stationary_conv_is_reproducible_and_gated(monkeypatch):
     _, _, _, b = _ws_forms(2, 300, 500, 11)
     for k in a:
         assert torch.equal(a[k], b[k]), k
-    # images below two tiles per CU, other widths and strides stay on the streaming kernel: same bits with the switch on or off
+    # images below 192 tiles, other widths and strides stay on the streaming kernel: same bits with the switch on or off
     torch.manual_seed(3)
     for cin, cout, H, W, stride in ((64, 64, 96, 160, 1), (64, 96, 264, 544, 1), (64, 64, 264, 544, 2)):
         layer = nn.Conv2d(cin, cout, 3, padding=1, stride=stride).to(DEV)
