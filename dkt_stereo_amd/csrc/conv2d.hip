@@ -397,53 +397,60 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
             }
             if (a.stats_ws) {
                 // sums / sums of squares of the values just stored: per lane over its NF pixels, then a reduce-scatter over the
-                // 32 pixel lanes of the half-wave (31 exchanges per statistic instead of 160): lane li ends with value index li
-                constexpr int NV = MF * 16;
-                float s1[NV], s2[NV];
+                // 32 pixel lanes of the half-wave (31 exchanges per statistic instead of 160): lane li ends with value index li.
+                // Channel blocks go in groups of two (32 values per lane) and, for an odd MF, a last single one (16 values: the
+                // first exchange only adds, lane li & 15 ends with value li & 15).
+                auto stats_group = [&](const int m0, const int nm) {
+                    float s1[32], s2[32];
 #pragma unroll
-                for (int i = 0; i < NV; ++i) s1[i] = s2[i] = 0.0f;
+                    for (int i = 0; i < 32; ++i) s1[i] = s2[i] = 0.0f;
 #pragma unroll
-                for (int n = 0; n < NF; ++n) {
-                    const int oh = h0 + wn * NF + n, ow = w0 + li;
-                    const bool ok = oh < a.Ho && ow < a.Wo;
+                    for (int n = 0; n < NF; ++n) {
+                        const int oh = h0 + wn * NF + n, ow = w0 + li;
+                        const bool ok = oh < a.Ho && ow < a.Wo;
 #pragma unroll
-                    for (int m = 0; m < MF; ++m)
+                        for (int mm = 0; mm < nm; ++mm)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float v = acc[m][n][r] * a.out_scale + bv[m][r];
-                            if (a.relu) v = dkt_relu(v);
-                            v = ok ? v : 0.0f;
-                            s1[m * 16 + r] = __fadd_rn(s1[m * 16 + r], v);
-                            s2[m * 16 + r] = __fadd_rn(s2[m * 16 + r], __fmul_rn(v, v));
+                            for (int r = 0; r < 16; ++r) {
+                                float v = acc[m0 + mm][n][r] * a.out_scale + bv[m0 + mm][r];
+                                if (a.relu) v = dkt_relu(v);
+                                v = ok ? v : 0.0f;
+                                s1[mm * 16 + r] = __fadd_rn(s1[mm * 16 + r], v);
+                                s2[mm * 16 + r] = __fadd_rn(s2[mm * 16 + r], __fmul_rn(v, v));
+                            }
+                    }
+                    if (nm == 1) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            s1[i] = __fadd_rn(s1[i], __shfl_xor(s1[i], 16, 32));
+                            s2[i] = __fadd_rn(s2[i], __shfl_xor(s2[i], 16, 32));
                         }
-                }
-                if (NV == 16) {          // 16 values on 32 lanes: the first exchange only adds
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        s1[i] = __fadd_rn(s1[i], __shfl_xor(s1[i], 16, 32));
-                        s2[i] = __fadd_rn(s2[i], __shfl_xor(s2[i], 16, 32));
                     }
-                }
 #pragma unroll
-                for (int d = (NV == 16 ? 8 : 16); d >= 1; d >>= 1) {
-                    const bool up = (li & d) != 0;
+                    for (int d = 16; d >= 1; d >>= 1) {
+                        if (nm == 1 && d == 16) continue;
+                        const bool up = (li & d) != 0;
 #pragma unroll
-                    for (int j = 0; j < d; ++j) {
-                        const float k1 = up ? s1[j + d] : s1[j], g1 = up ? s1[j] : s1[j + d];
-                        const float k2 = up ? s2[j + d] : s2[j], g2 = up ? s2[j] : s2[j + d];
-                        s1[j] = __fadd_rn(k1, __shfl_xor(g1, d, 32));
-                        s2[j] = __fadd_rn(k2, __shfl_xor(g2, d, 32));
+                        for (int j = 0; j < d; ++j) {
+                            const float k1 = up ? s1[j + d] : s1[j], g1 = up ? s1[j] : s1[j + d];
+                            const float k2 = up ? s2[j + d] : s2[j], g2 = up ? s2[j] : s2[j + d];
+                            s1[j] = __fadd_rn(k1, __shfl_xor(g1, d, 32));
+                            s2[j] = __fadd_rn(k2, __shfl_xor(g2, d, 32));
+                        }
                     }
-                }
-                const int vi = NV == 16 ? (li & 15) : li;                 // value index this lane holds
-                const int dco = (vi >> 4) * 32 + (vi & 3) + 8 * ((vi & 15) >> 2);
-                const int co = co_lane + dco;
-                const long e = (long)((h0 / (NF * WN)) * a.tiles_w + w0 / 32) * WN + wn;
-                if (co < a.Cout && (NV == 32 || li < 16)) {
-                    float *p = a.stats_ws + (((long)b * a.tiles_xy * WN + e) * a.Cout + co) * 2;
-                    p[0] = s1[0];
-                    p[1] = s2[0];
-                }
+                    const int vi = nm == 1 ? (li & 15) : li;                 // value index this lane holds
+                    const int dco = (m0 + (vi >> 4)) * 32 + (vi & 3) + 8 * ((vi & 15) >> 2);
+                    const int co = co_lane + dco;
+                    const long e = (long)((h0 / (NF * WN)) * a.tiles_w + w0 / 32) * WN + wn;
+                    if (co < a.Cout && (nm == 2 || li < 16)) {
+                        float *p = a.stats_ws + (((long)b * a.tiles_xy * WN + e) * a.Cout + co) * 2;
+                        p[0] = s1[0];
+                        p[1] = s2[0];
+                    }
+                };
+#pragma unroll
+                for (int m0 = 0; m0 + 1 < MF; m0 += 2) stats_group(m0, 2);
+                if (MF & 1) stats_group(MF - 1, 1);
             }
             return;
         }
@@ -745,6 +752,7 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const Con
                 if (tiles4 / 2 >= 512) return launch_conv<KS, 1, 4, 2, PASSES, 2, 1, 1, 1>(a, B, st);
                 return launch_conv<KS, 1, 4, 1, PASSES, 2, 1, 2, 1>(a, B, st);
             }
+            if (a.Cout > 64 && a.Cout <= 96 && tiles4 >= CONV_FEW_TILES) return launch_conv<KS, 1, 4, 1, PASSES, 3, 1, 2, 1>(a, B, st);
             if (a.Cout > 64 && a.Cout <= 128) {
                 if (tiles4 < CONV_FEW_TILES) return launch_conv<KS, 2, 2, 1, PASSES, 2, 1, 2, 1>(a, B, st);
                 return launch_conv<KS, 2, 2, 2, PASSES, 2, 1, 2, 1>(a, B, st);
@@ -769,6 +777,11 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const Con
         return launch_conv<KS, 1, 4, 1, PASSES>(a, B, st, sec);                          // 64 co x 4 rows
     }
     if (a.Cout <= 128) {
+        // 65 .. 96 channels: a 96-channel wave tile (three 32-channel blocks per wave, four waves on rows) instead of padding
+        // a quarter of the 128-channel tile's MFMAs and weight fragments: 96->96 @368x624 205 -> 181 us, two images 357 -> 330
+        if constexpr (KS == 3) {
+            if (a.Cout <= 96 && !sec && tiles4 >= few) return launch_conv<KS, 1, 4, 1, PASSES, 3>(a, B, st);
+        }
         if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st, sec);        // 128 co x 2 rows
         return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st, sec);                          // 128 co x 4 rows
     }

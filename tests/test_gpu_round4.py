@@ -229,7 +229,8 @@ def test_default_path_holds_the_bound_when_activations_sit_at_1e_3_or_1e3(k, gol
 
 @torch.no_grad()
 @pytest.mark.parametrize("shape", [(2, 64, 64, 96, 160, 1, 3), (2, 64, 96, 96, 160, 2, 3), (1, 96, 128, 47, 81, 2, 3),
-                                   (2, 64, 96, 90, 130, 2, 1), (1, 128, 128, 40, 72, 1, 3), (3, 32, 40, 33, 70, 1, 3)])
+                                   (2, 64, 96, 90, 130, 2, 1), (1, 128, 128, 40, 72, 1, 3), (3, 32, 40, 33, 70, 1, 3),
+                                   (2, 96, 96, 93, 157, 1, 3), (1, 96, 80, 120, 200, 1, 3)])      # the 96-channel wave tile (three blocks per wave)
 def test_conv_epilogue_statistics_match_the_statistics_pass(shape):
     """dkt_conv_desc.stats_ws: the (mean, 1/std) an InstanceNorm2d needs of a convolution's output, accumulated in the
     convolution's epilogue, against dkt_instance_norm_stats on the written output and against torch in fp64 -- every tile
@@ -455,3 +456,31 @@ def test_weights_stationary_conv_is_reproducible_and_gated(monkeypatch):
             monkeypatch.setenv("DKT_CONV_WS", "0")
             y0 = conv.conv2d(x, layer, relu=True)
         assert torch.equal(y0, y1), (cin, cout, H, W, stride)
+
+
+@pytest.mark.parametrize("cout", [96, 72])
+def test_ninety_six_channel_tile_matches_fp64_in_every_form(cout):
+    """65 .. 96 output channels run on a 96-channel wave tile (conv2d.hip: launch_conv<3, 1, 4, 1, P, 3>): plain / ReLU /
+    residual join / instance-norm input + output statistics against fp64 (the layers of core/extractor.py's layer2)."""
+    import torch.nn as nn
+    from dkt_stereo_amd import conv
+    from dkt_stereo_amd.extractor import instance_norm_params
+    torch.manual_seed(cout)
+    B, H, W = 2, 93, 157
+    layer = nn.Conv2d(96, cout, 3, padding=1).to(DEV)
+    x = torch.randn(B, 96, H, W, device=DEV) * 2 + 0.3
+    res = torch.randn(B, cout, H, W, device=DEV).relu()
+    w, b = layer.weight.detach().double(), layer.bias.detach().double()
+    with torch.no_grad():
+        ref = F.conv2d(x.double(), w, b, padding=1)
+        assert _rel(conv.conv2d(x, layer), ref) < 2.5e-6
+        assert _rel(conv.conv2d(x, layer, relu=True), ref.relu()) < 2.5e-6
+        assert _rel(conv.conv2d_fused(x, layer, relu=True, residual=res), (res.double() + ref.relu()).relu()) < 2.5e-6
+        p = instance_norm_params(nn.InstanceNorm2d(96), x)
+        refn = F.conv2d(F.instance_norm(x.double()).relu(), w, b, padding=1)
+        y, st = conv.conv2d_stats(x, layer, in_norm=p)
+        assert _rel(y, refn) < 2.5e-6
+        got = instance_norm_params(nn.InstanceNorm2d(cout), y, st)
+        mean = refn.mean(dim=(2, 3)).reshape(-1)
+        istd = (refn.var(dim=(2, 3), unbiased=False) + 1e-5).rsqrt().reshape(-1)
+        assert _rel(got[:, 0], mean) < 4e-6 and _rel(got[:, 1], istd) < 4e-6
