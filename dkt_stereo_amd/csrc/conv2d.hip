@@ -805,8 +805,11 @@ static int launch_conv_stride2(const ConvArgs &a, int B, hipStream_t st) {
     if constexpr (KS == 3 && PASSES == 3) {
         // 128 co x 4 rows with 16-channel chunks (9 x 65 patch, 56 KB per stage, one block per CU): twice the MFMAs per weight
         // fragment of the 2-row form -- 64->96 @736x1248 281 -> 243 us, two images 518 -> 422; 96->128 @368x624 x 2: 174 -> 138
-        if (a.Cout <= 128 && (long)a.tiles_w * ((a.Ho + 3) / 4) * B >= 512)
+        if (a.Cout <= 128 && (long)a.tiles_w * ((a.Ho + 3) / 4) * B >= 512) {
+            // (up to 96 channels: the 96-channel wave tile, as for stride 1 -- 243 -> 223 us, two images 422 -> 395)
+            if (a.Cout <= 96) return launch_conv<KS, 1, 4, 1, PASSES, 3, 2, 1>(a, B, st);
             return launch_conv<KS, 2, 2, 2, PASSES, 2, 2, 1>(a, B, st);
+        }
     }
     if (a.Cout <= 128) return launch_conv<KS, 2, 2, 1, PASSES, 2, 2>(a, B, st);   // 128 co x 2 rows
     return launch_conv<KS, 4, 1, 1, PASSES, 2, 2>(a, B, st);                      // 256 co x 1 row

@@ -230,7 +230,8 @@ def test_default_path_holds_the_bound_when_activations_sit_at_1e_3_or_1e3(k, gol
 @torch.no_grad()
 @pytest.mark.parametrize("shape", [(2, 64, 64, 96, 160, 1, 3), (2, 64, 96, 96, 160, 2, 3), (1, 96, 128, 47, 81, 2, 3),
                                    (2, 64, 96, 90, 130, 2, 1), (1, 128, 128, 40, 72, 1, 3), (3, 32, 40, 33, 70, 1, 3),
-                                   (2, 96, 96, 93, 157, 1, 3), (1, 96, 80, 120, 200, 1, 3)])      # the 96-channel wave tile (three blocks per wave)
+                                   (2, 96, 96, 93, 157, 1, 3), (1, 96, 80, 120, 200, 1, 3), (2, 64, 96, 264, 544, 2, 3),
+                                   (2, 96, 128, 264, 544, 2, 3)])      # the 96-channel wave tile (three blocks per wave)
 def test_conv_epilogue_statistics_match_the_statistics_pass(shape):
     """dkt_conv_desc.stats_ws: the (mean, 1/std) an InstanceNorm2d needs of a convolution's output, accumulated in the
     convolution's epilogue, against dkt_instance_norm_stats on the written output and against torch in fp64 -- every tile
