@@ -101,6 +101,11 @@ struct ConvArgs {
     float *stats_ws;
     double *stats_part;
     long stats_hw;       // filled by launch_conv: plane size of the output
+    // Sub-sampled sources (a 1x1 stride-2 projection run as a 1x1 stride-1 layer on every second pixel of every second row:
+    // the tiled stride-2 form stages the odd rows and columns it never uses -- three quarters of its requests): H, W are the
+    // OUTPUT size, src_px the pixel stride in the source, src_w / src_hw its row pitch and plane size.  Plain layers: 1, W, H*W.
+    int src_px, src_w;
+    long src_hw;
 };
 int conv_stats_reduce(const float *ws, double *part, int B, int C, long entries, long HW, hipStream_t st);      // norm.hip
 
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const long HW = (long)a.H * a.W;
+    const long SHW = a.src_hw;              // plane size of the sources (== HW unless they are sub-sampled)
     // Persistent block: tiles t = (block index within its problem), + (blocks of that problem), ...; the (tile, chunk)
     // pairs of a block form ONE software-pipelined stream, so that only the block's first
     // chunk is staged with its global-load latency exposed (for a 64->64 layer -- two chunks
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
             const int pr = pp / PC, pc = pp - pr * PC;
             const int ih = th0 * ST - HALO + pr, iw = tw0 * ST - HALO + pc;
             sok[it] = pp < NPP && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            spix[it] = sok[it] ? (unsigned)(ih * a.W + iw) * 4u : 0u;
+            spix[it] = sok[it] ? (unsigned)((ih * a.src_w + iw) * a.src_px) * 4u : 0u;
         }
     };
     auto stage_select = [&](int tb, int chunk) {
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
         }
         const int cb = c0 + 8 * swave;
         snch = a.src_ch[s] - cb;
-        sbase = a.src[s] + (long)tb * a.src_bs[s] + (long)(snch > 0 ? cb : 0) * HW;
+        sbase = a.src[s] + (long)tb * a.src_bs[s] + (long)(snch > 0 ? cb : 0) * SHW;
         if (NRM) {
             const float *np = a.in_norm + 2 * ((long)tb * a.src_ch[0] + (snch > 0 ? cb : 0));
 #pragma unroll
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
                 // select here would tie an s_waitcnt vmcnt(0) to every load
                 const int j = 2 * q + jj;
                 const int jc = min(j, max(snch, 1) - 1);                     // wave-uniform
-                const char *pj = (const char *)(sbase + (long)jc * HW);
+                const char *pj = (const char *)(sbase + (long)jc * SHW);
                 sreg[it][j] = *(const float *)(pj + spix[it]);
             }
         }
@@ -826,6 +832,13 @@ template <int PASSES>
 static int conv2d_launch_passes(const ConvArgs &a, int B, int KH, int stride, hipStream_t st, const ConvSecond *sec) {
     if (stride == 2) {
         if (sec || a.in_norm) return DKT_E_UNSUPPORTED;
+        if (KH == 1) {
+            // 1x1, stride 2 = the 1x1 stride-1 layer on the even pixels of the even rows (see ConvArgs::src_px)
+            ConvArgs v = a;
+            v.H = a.Ho; v.W = a.Wo;
+            v.src_px = 2; v.src_w = a.W; v.src_hw = (long)a.H * a.W;
+            return launch_conv_shape<1, PASSES>(v, B, st, nullptr);
+        }
 
         if (KH == 3) return launch_conv_stride2<3, PASSES>(a, B, st);
         return launch_conv_stride2<1, PASSES>(a, B, st);
@@ -896,6 +909,7 @@ static int conv_fill(ConvArgs &a, const float *const *src, const int *src_channe
     a.stats_ws = nullptr;
     a.stats_part = nullptr;
     a.stats_hw = 0;
+    a.src_px = 1; a.src_w = W; a.src_hw = (long)H * W;
     if (epi) {
         a.epi = epi->kind;
         a.e_c0 = epi->c0; a.e_c1 = epi->c1; a.e_h = epi->h;
