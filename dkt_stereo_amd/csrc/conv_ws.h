@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned ws_bits(ws_h2 h) {
 
 template <int NRM, int EPI>
 __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
-    constexpr int KS = 3, HALO = 1;
+    constexpr int HALO = 1;
     constexpr int NF = 4, WN = 2;            // rows per wave, waves along rows
     constexpr int TR = NF * WN;              // 8 output rows per block
     constexpr int PR = TR + 2, PC = 34, NPP = PR * PC;
@@ -51,7 +51,6 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
     constexpr int PLANE = NPP * PITCH;
     constexpr int STAGE = 2 * PLANE;         // hi + lo
     constexpr int NCH = 4;                   // 16-channel chunks of the 64 input channels
-    constexpr int NSTEP = 3 * (NF + 2);      // (dx, patch row) steps per chunk
     constexpr int NG = 16;                   // issue groups per chunk (conv_ws_group_first)
     constexpr int RB = 4;                    // B-fragment ring: reads run two groups ahead
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];   // 2 * STAGE words (+ 8 dummy)
@@ -454,6 +453,7 @@ static bool conv_ws_eligible(const ConvArgs &a, int B) {
     if (a.nsrc != 1 || a.src_ch[0] != 64 || a.Cout != 64 || a.nch16 != 4 || a.CoutPad != 64) return false;
     if (a.epi != 0 && a.epi != 3) return false;
     if (a.Ho != a.H || a.Wo != a.W || B > 64) return false;
+    if ((long)a.H * a.W * 128 > 0x7fffffffL) return false;     // 32 output planes per buffer descriptor, byte offsets in 32 bits
     const long tiles = (long)a.tiles_w * ((a.H + 7) / 8) * B;
     return tiles >= 192;           // measured: 22 against 30 us at 230 tiles (184 x 312), equal at 128, 35 against 45-48 at 512
 }
