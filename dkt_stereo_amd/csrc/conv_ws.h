@@ -485,7 +485,14 @@ static int launch_conv_ws(ConvArgs a, int B, hipStream_t st) {
     if (total > 0x7fffffffL) return DKT_E_SHAPE;
     a.total_tiles = (int)total;
     const long cap = ready[dev & 63];
-    const long nblk = total > cap ? cap : total;
+    // no more blocks than the rounds need (3588 tiles are 15 rounds on 256 CUs and on 240): the spare CUs stay free for the
+    // other encoder's stream; a multiple of 8 keeps the XCD mapping
+    long nblk = total > cap ? cap : total;
+    if (total > cap) {
+        const long rounds = (total + cap - 1) / cap;
+        const long need = ((total + rounds - 1) / rounds + 7) & ~7L;
+        if (need < nblk) nblk = need;
+    }
     void *params[1] = {(void *)&a};
     (void)hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(256), params, lds, st);
     int rc = dkt_launch_status();
