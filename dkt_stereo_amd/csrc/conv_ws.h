@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256, 1) void conv64_ws_kernel(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
+            // (a raw barrier behind the wave's own LDS traffic: __syncthreads() also drains the memory counter -- the activation
+            // requests of the next chunk and the previous tile's stores -- at every chunk)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             // @trace(1 + c)
             if (c + 1 < NCH) {           // (the next tile's first fragments are read behind the epilogue: 16 registers it needs)
                 loadB(0, nxt, 0);
