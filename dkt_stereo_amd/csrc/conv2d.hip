@@ -791,6 +791,13 @@ static int launch_conv_shape(const ConvArgs &a, int B, hipStream_t st, const Con
         if (tiles4 < few) return launch_conv<KS, 2, 2, 1, PASSES>(a, B, st, sec);        // 128 co x 2 rows
         return launch_conv<KS, 2, 2, 2, PASSES>(a, B, st, sec);                          // 128 co x 4 rows
     }
+    // 257 .. 384 channels (the context encoder's 128 -> 3 x 128 projection, raft_stereo.py:103-106) on large images: four waves of
+    // 96 channels each and two rows -- the patch is staged once and no channel block is padding, where the 256-channel tile runs
+    // a second, half-empty block: 253 -> 213 us @184x312 (slower below ~500 tiles: 65 -> 70 us @92x156)
+    if constexpr (KS == 3) {
+        if (a.Cout > 256 && a.Cout <= 384 && !sec && (long)a.tiles_w * ((a.H + 1) / 2) * B >= 512)
+            return launch_conv<KS, 4, 1, 2, PASSES, 3>(a, B, st);
+    }
     const long tiles2 = (long)a.tiles_w * ((a.H + 1) / 2) * B * ((a.Cout + 255) / 256);
     if (tiles2 < few) return launch_conv<KS, 4, 1, 1, PASSES>(a, B, st, sec);            // 256 co x 1 row
     // wide layers on large images: ONE block of 8 waves per CU, 256 co x 4 rows (WM x WN = 4 x 2): the two
