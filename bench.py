@@ -470,7 +470,7 @@ def main():
                    # GPU): its weak-scaling reference is `--gpus 1 --batch 8` (profiles/r03_bench_lines.jsonl, line 2)
                    "per_gpu_batch": B,
                    "weak_scaling_reference": "bench.py --gpus 1 --batch %d" % B,
-                   "conv_backend": (conv_backend_name.replace("dkt_conv2d_f16s", "refinement loop: dkt_conv2d_c8, encoders: dkt_conv2d_f16s")
+                   "conv_backend": (conv_backend_name.replace("dkt_conv2d_f16s", "refinement loop: dkt_conv2d_c8, encoders: dkt_conv2d_f16s incl. the weights-stationary 64->64 kernel")
                                     if (c8_used or gru_used) else conv_backend_name),
                    "loop": ("C8S convolutions (loop_c8.py), fused ConvGRU launch" if gru_used else
                             "C8S convolutions (loop_c8.py)" if c8_used else "round-2 kernels")},
