@@ -14,9 +14,11 @@ hot path (captured loop, fused epilogues); ``test_mode=False`` with autograd ena
 is the training forward (tools/ft_dkt.py:223): every iteration's prediction, the
 correlation block and the update operator as autograd nodes on this library's kernels.
 """
+import itertools
 import os
 import threading
 import weakref
+from concurrent.futures import ThreadPoolExecutor
 from types import SimpleNamespace
 
 import torch
@@ -72,6 +74,69 @@ _GRAPH_LOCK = threading.Lock()
 _HANDOVER = threading.local()
 
 
+class _Shadow:
+    """One persistent copy of a model on one device of an nn.DataParallel group, and the one thread that drives it.
+
+    nn.DataParallel (tools/ft_dkt.py:119-125: the student, the teacher and its EMA twin; test_mode=True for the teachers,
+    :193,199) hands every forward NEW replica modules with NEW parameter tensors, each on a NEW Python thread
+    (torch.nn.parallel.parallel_apply).  The captured loop, the packed weight images and the per-thread side streams of
+    this library are keyed by module, weight storage and thread: on a replica they would be rebuilt on every call, which is
+    why replicas used to run the plain un-captured loop (missing #6).  Instead a replica's test_mode forward
+    is handed to this object: a full copy of the master on the replica's device whose weights are refreshed (in place, so
+    its caches notice) when the master's have changed, driven by a single worker thread that lives as long as the master,
+    so that every thread-keyed state persists between forwards.  The worker issues on the device's current (default)
+    stream, the one DataParallel's scatter leaves the inputs ready on."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.model = None
+        self.fingerprint = None
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dkt-replica-cuda%d" % self.device.index)
+
+    @staticmethod
+    def _tensors(m):
+        return list(itertools.chain(m.parameters(), m.buffers()))
+
+    def _sync(self, master):
+        src = self._tensors(master)
+        fp = tuple((t.data_ptr(), t._version) for t in src)
+        if self.model is None:
+            self.model = type(master)(master.args).to(self.device)
+            self.model._is_shadow = True
+        if fp != self.fingerprint:
+            with torch.no_grad():
+                for d, t in zip(self._tensors(self.model), src):
+                    d.copy_(t)
+            self.fingerprint = fp
+        for a, b in zip(master.modules(), self.model.modules()):
+            b.training = a.training                                  # freeze_bn() and eval() of the master
+        for k, v in master.__dict__.items():                         # switches set on the instance (use_hip_graph, ...)
+            if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str)):
+                setattr(self.model, k, v)
+
+    def _run(self, master, backend, args, kwargs):
+        torch.cuda.set_device(self.device)
+        with _conv.use_backend(backend):
+            self._sync(master)
+            return self.model(*args, **kwargs)
+
+    def run(self, master, *args, **kwargs):
+        return self.pool.submit(self._run, master, _conv.get_backend(), args, kwargs).result()
+
+
+_SHADOWS = weakref.WeakKeyDictionary()             # master module -> {device index: _Shadow}
+_SHADOW_LOCK = threading.Lock()
+
+
+def _shadow_of(master, device):
+    with _SHADOW_LOCK:
+        per = _SHADOWS.setdefault(master, {})
+        sh = per.get(device.index)
+        if sh is None:
+            sh = per[device.index] = _Shadow(device)
+        return sh
+
+
 class RAFTStereo(nn.Module):
     @property
     def _graph_state(self):
@@ -101,6 +166,15 @@ class RAFTStereo(nn.Module):
             [nn.Conv2d(context_dims[i], args.hidden_dims[i] * 3, 3, padding=3 // 2)
              for i in range(args.n_gru_layers)])
         self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', downsample=args.n_downsample)
+
+    #: a replica made by nn.DataParallel runs its test_mode forward on a persistent per-device copy of the master (_Shadow):
+    #: captured loop and packed weights survive between forwards.  False: replicas run the plain loop themselves
+    replica_shadows = True
+
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica._dp_master = weakref.ref(self)
+        return replica
 
     def freeze_bn(self):
         for m in self.modules():
@@ -733,6 +807,10 @@ class RAFTStereo(nn.Module):
             if not finite:
                 raise _ffi.DktError("RAFTStereo.forward(test_mode=False) produced non-finite disparities")
             return out
+        if getattr(self, "_is_replica", False) and self.replica_shadows and image1.is_cuda:
+            master = getattr(self, "_dp_master", lambda: None)()
+            if master is not None:
+                return _shadow_of(master, image1.device).run(master, image1, image2, iters=iters, flow_init=flow_init, test_mode=True)
         with torch.no_grad():
             return self._forward_test(image1, image2, iters, flow_init)
 

@@ -825,3 +825,89 @@ def test_lazy_residual_operand_of_the_instance_norm_join(relu):
     got = extractor.norm_add_relu(norm, extractor.LazyNorm(norm, a, relu), c)
     assert torch.equal(got, want)
     assert torch.equal(extractor.LazyNorm(norm, a, relu).materialize(), extractor.norm_act(norm, a, relu))
+
+
+@torch.no_grad()
+def test_data_parallel_replicas_run_on_a_persistent_shadow():
+    """nn.DataParallel (tools/ft_dkt.py:119-125; the teachers are called with test_mode=True, :193,199) makes new replica
+    modules on new threads for every forward.  A replica's test_mode forward goes to a persistent per-device copy of the
+    master driven by one long-lived worker thread (raft_stereo._Shadow): the loop is captured ONCE and replayed by later
+    forwards, the result equals the master's own forward bit for bit, and a weight update on the master reaches the copy."""
+    from dkt_stereo_amd import raft_stereo as rs
+    model, _ = _raft()
+    a, b = (G(x) for x in _synth.image_pair(3, 1, 64, 128, 12))
+    want = model(a, b, iters=7, test_mode=True)[1].clone()
+
+    def through_replicas(n):
+        # what DataParallel.forward does with the master: replicate, then one NEW thread per replica (parallel_apply)
+        reps = [model._replicate_for_data_parallel() for _ in range(n)]
+        out, err = [None] * n, []
+
+        def run(k):
+            try:
+                with torch.no_grad():
+                    out[k] = reps[k](a, b, iters=7, test_mode=True)[1].clone()
+            except Exception as e:        # noqa: BLE001
+                err.append(e)
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not err, err
+        return out
+
+    assert all(r._is_replica for r in [model._replicate_for_data_parallel()])
+    for o in through_replicas(2):
+        assert torch.equal(o, want)
+    shadow = rs._SHADOWS[model][torch.device(DEV).index]
+    assert shadow.model is not model and shadow.model.training == model.training
+    state = rs._GRAPH_STATES[shadow.model]
+    assert len(state) == 1                                   # one thread has ever driven the copy ...
+    st = next(iter(state.values()))                          # (captured units and static buffers of the loop)
+    for o in through_replicas(2):
+        assert torch.equal(o, want)
+    assert len(rs._GRAPH_STATES[shadow.model]) == 1          # ... and the later forwards replayed its capture
+    assert next(iter(rs._GRAPH_STATES[shadow.model].values())) is st
+    # a weight update on the master (the EMA teacher of tools/ft_dkt.py changes every step) reaches the copy
+    model.update_block.flow_head.conv2.weight.mul_(1.5)
+    want2 = model(a, b, iters=7, test_mode=True)[1].clone()
+    assert not torch.equal(want2, want)
+    for o in through_replicas(2):
+        assert torch.equal(o, want2)
+    # the switch: replicas on their own (the plain loop), same numbers within the loop's reassociation
+    model.replica_shadows = False
+    o = through_replicas(1)[0]
+    assert maxabs(o, want2) <= 1e-3
+
+
+@torch.no_grad()
+def test_data_parallel_wrapper_single_device():
+    """tools/evaluate_stereo.py:361: DataParallel(model, device_ids=[0]) calls the master itself (no replication)."""
+    model, _ = _raft()
+    a, b = (G(x) for x in _synth.image_pair(3, 1, 64, 128, 12))
+    want = model(a, b, iters=7, test_mode=True)[1].clone()
+    dp = torch.nn.DataParallel(model, device_ids=[torch.cuda.current_device()])
+    assert torch.equal(dp(a, b, iters=7, test_mode=True)[1], want)
+
+
+@torch.no_grad()
+def test_data_parallel_wrapper_two_replicas():
+    """tools/ft_dkt.py:122-125,193,199: the teachers under nn.DataParallel with test_mode=True.  One device listed twice
+    gives torch's own replicate / scatter / parallel_apply / gather with two replicas on a 1-GPU box: both chunks of the
+    batch come back as the master's own result for that pair, and a second call replays the captured loop of the copy."""
+    from dkt_stereo_amd import raft_stereo as rs
+    model, _ = _raft()
+    pairs = [_synth.image_pair(s, 1, 64, 128, sh) for s, sh in ((3, 12), (4, 20))]
+    a = torch.cat([G(p[0]) for p in pairs])
+    b = torch.cat([G(p[1]) for p in pairs])
+    want = model(a[:1], b[:1], iters=7, test_mode=True)[1].clone()         # (chunk 0 first: the pair the scales are picked on)
+    want = torch.cat([want, model(a[1:], b[1:], iters=7, test_mode=True)[1]])
+    dev = torch.device(DEV).index
+    dp = torch.nn.DataParallel(model, device_ids=[dev, dev])
+    for _ in range(2):
+        low, up = dp(a, b, iters=7, test_mode=True)
+        assert up.shape == want.shape and low.shape[0] == 2
+        assert maxabs(up, want) <= 2e-4                                   # (chunk order on the copy's thread is not fixed:
+    assert len(rs._GRAPH_STATES[rs._SHADOWS[model][dev].model]) == 1      #  the scales may come from either pair)
