@@ -66,8 +66,10 @@ def eligible(model, shape=None):
     return _eligible_block(model.update_block, shape, 126)
 
 
-#: IGEV keeps the round-2 loop below this many quarter-resolution pixels (its small shapes have not been measured on this loop)
-IGEV_MIN_PIXELS = 24000
+#: IGEV would keep the round-2 loop below this many quarter-resolution pixels.  0 since the end of round 4: every size measured
+#: takes this loop (tools/igev_small_shapes.py, profiles/r04_igev_small_shapes.txt: 64x128 ... 160x256 at 1/4 resolution
+#: 8.6 ... 20.9 ms per 32 iterations against 11.5 ... 28.9 on the round-2 loop, results 1e-5 apart)
+IGEV_MIN_PIXELS = 0
 
 
 def eligible_igev(ub, shape=None):

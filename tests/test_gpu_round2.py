@@ -91,13 +91,17 @@ def test_igev_loop_fixtures(name, golden):
     assert maxabs(got_m[:, :, ::st, ::st], g[name + "/mask"]) <= 1e-3
 
 
+@pytest.mark.parametrize("c8", [False, True])
 @torch.no_grad()
-def test_igev_iterate_new_volume_per_pair_and_weight_change():
-    """The reference builds a new Combined_Geo_Encoding_Volume for every pair (igev_stereo.py:192-193).
+def test_igev_iterate_new_volume_per_pair_and_weight_change(c8, monkeypatch):
+    """(c8 = False: the round-2 loop, bit-identical to the plain loop; True: the default loop_c8, within the split-fp16 class.)
+    The reference builds a new Combined_Geo_Encoding_Volume for every pair (igev_stereo.py:192-193).
     With a persistent cache the captured graph must follow: (1) a new volume object of the same shapes,
     (2) the same volume rebuilt in place, (3) changed weights (load_state_dict after the first capture)."""
     from dkt_stereo_amd.geometry import Combined_Geo_Encoding_Volume
+    from dkt_stereo_amd import igev_loop
     from dkt_stereo_amd.igev_loop import _plain, igev_iterate
+    monkeypatch.setattr(igev_loop, "USE_C8", c8)
     c = dict(_cases.IGEV_LOOP_CASES["small"], H=16, W=32)
     blk, geo_a, d0, coords, net, inp, (m1, m2, geo) = _igev_setup(c)
     cache = {}
@@ -106,11 +110,18 @@ def test_igev_iterate_new_volume_per_pair_and_weight_change():
     def both(geo_fn):
         want = _plain(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, iters)
         got = igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, iters, cache=cache)
-        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        if c8:
+            assert maxabs(got[0], want[0]) <= 2e-4 and maxabs(got[1], want[1]) <= 2e-4
+        else:
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
         return got[0]
 
+    def the_graph():
+        return cache["state"].c8.graph if c8 else cache["state"].graph
+
     r_a = both(geo_a)
-    graph = cache["state"].graph
+    graph = the_graph()
+    assert graph is not None
     del geo_a
     # (1) new object, other content; many allocations in between so that ids / addresses get recycled
     geo2 = _synth.normal(geo.shape, 77, "geo2")
@@ -118,17 +129,17 @@ def test_igev_iterate_new_volume_per_pair_and_weight_change():
     geo_b = Combined_Geo_Encoding_Volume(G(m2), G(m1), G(geo2), radius=4, num_levels=2)
     del junk
     r_b = both(geo_b)
-    assert cache["state"].graph is graph                 # replayed, not re-captured
+    assert the_graph() is graph                          # replayed, not re-captured
     assert not torch.equal(r_a, r_b)
     # (2) the cached volume rebuilt in place by the caller
     cache["state"].geo_fn.rebuild(G(m1), G(m2), G(geo))
     r_c = both(cache["state"].geo_fn)
-    assert torch.equal(r_c, r_a) and cache["state"].graph is graph
+    assert torch.equal(r_c, r_a) and the_graph() is graph
     # (3) weights change -> fresh capture, results follow the new weights
     sd = {k: v * 1.01 for k, v in blk.state_dict().items()}
     blk.load_state_dict(sd)
     r_d = both(cache["state"].geo_fn)
-    assert cache["state"].graph is not graph
+    assert the_graph() is not graph
     assert not torch.equal(r_d, r_a)
 
 
