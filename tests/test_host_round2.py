@@ -256,3 +256,38 @@ def test_capture_guard_excludes_other_forwards():
     assert overlap[0] == 0 and len(order) == 60
     with g.exclusive():                             # also usable without holding it shared
         pass
+
+
+def test_data_parallel_replica_knows_its_master_and_the_copy_follows_it():
+    """torch.nn.parallel.replicate calls _replicate_for_data_parallel on the master (tools/ft_dkt.py:119-125): the replica
+    keeps a weak reference to it (its test_mode forward on a GPU goes to the master's persistent per-device copy,
+    raft_stereo._Shadow); the copy's refresh logic -- weights when the master's versions change, training flags, instance
+    switches -- is plain host code and is checked here on the CPU."""
+    import gc
+    from dkt_stereo_amd import raft_stereo as rs
+    model = rs.RAFTStereo()
+    model.eval()
+    rep = model._replicate_for_data_parallel()
+    assert rep._is_replica and rep._dp_master() is model and not getattr(model, "_is_replica", False)
+    sh = rs._Shadow.__new__(rs._Shadow)                 # (no worker thread, no device: _sync alone)
+    sh.device, sh.model, sh.fingerprint = torch.device("cpu"), None, None
+    sh._sync(model)
+    assert sh.model is not model and not sh.model.training
+    for a, b in zip(sh._tensors(model), sh._tensors(sh.model)):
+        assert a.data_ptr() != b.data_ptr() and torch.equal(a, b)
+    fp = sh.fingerprint
+    sh._sync(model)
+    assert sh.fingerprint == fp                         # nothing changed: nothing copied
+    with torch.no_grad():
+        model.update_block.flow_head.conv2.weight.mul_(2.0)
+    model.use_hip_graph = False
+    model.train()
+    model.freeze_bn()
+    v = sh.model.update_block.flow_head.conv2.weight._version
+    sh._sync(model)
+    assert sh.fingerprint != fp and sh.model.update_block.flow_head.conv2.weight._version > v    # written in place: caches notice
+    assert torch.equal(sh.model.update_block.flow_head.conv2.weight, model.update_block.flow_head.conv2.weight)
+    assert sh.model.use_hip_graph is False and sh.model.training
+    assert all(not m.training for m in sh.model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    del rep, model
+    gc.collect()
