@@ -6,7 +6,7 @@ O=gpurun_out
 STEPS=${@:-tests prof bench micro trace stress stages pmc ws}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && export PYTHONPATH=$GRAFT_REPO_ROOT
 for s in $STEPS; do case $s in
-tests) python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/${R}_gputests.txt ;;
+tests) python -m pytest tests -q -m gpu 2>&1 | grep -v -E "^(RCCL|HIP|ROCm) version|^Hostname|^Librccl|amdgpu.ids" | tail -5 > $O/${R}_gputests.txt ;;
 prof)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof -o bench -- python bench.py --steps 3 --warmup 2 --skip-cpu-baseline > $O/${R}_prof_bench.log 2>&1
   T=$(find $O/${R}_prof -name "*kernel_trace.csv" | head -1)
