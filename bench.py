@@ -61,6 +61,9 @@ def parse():
     p.add_argument("--skip-cpu-baseline", action="store_true")
     p.add_argument("--pmc", action="store_true",
                    help="measure roofline.traffic in this run: two rocprofv3 --pmc sub-runs (FETCH_SIZE, WRITE_SIZE) of the reported launches")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="torch.distributed backend for --gpus > 1: nccl = RCCL over xGMI (default); gloo = host-staged, lets several "
+                        "ranks share one device (tests/test_gpu_round5.py exercises the N > 1 branch that way on a 1-GPU box)")
     p.add_argument("--conv-backend", default=None, choices=["f16x3", "f16x2", "f16", "miopen"],
                    help="update-block convolution path (default: the package default, f16x3)")
     a = p.parse_args()
@@ -97,16 +100,17 @@ class TimedCorr:
 
 def pmc_traffic(args):
     """HBM-side bytes per launch of the two reported kernels, measured now: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
-    in SEPARATE sub-runs (kernel trace only) of tools/pmc/pmc_probe_r04.py, which launches the same kernels on the same
-    shapes plus a known-traffic calibration stream; reads are FETCH_SIZE x the correction that stream yields."""
+    in SEPARATE sub-runs (kernel trace only) of tools/pmc/pmc_probe_r05.py, which runs this workload's forward with the loop's
+    units as plain launches plus a known-traffic calibration stream; reads are FETCH_SIZE x the correction that stream yields."""
     import subprocess
-    script = os.path.join(ROOT, "tools", "pmc", "run_pmc_r04.sh")
+    script = os.path.join(ROOT, "tools", "pmc", "run_pmc_r05.sh")
     try:
-        subprocess.run(["bash", script], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-        with open(os.path.join(ROOT, "gpurun_out", "r04_pmc", "traffic.json")) as f:
+        subprocess.run(["bash", script, str(args.batch)], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=2400)
+        sfx = "" if args.batch == 1 else "_b%d" % args.batch
+        with open(os.path.join(ROOT, "gpurun_out", "r05_pmc" + sfx, "traffic.json")) as f:
             j = json.load(f)
-        return {"conv_bytes": j.get("gru_bytes"), "lookup_bytes": j.get("lookup_conv1x1_b1_bytes"),
-                "note": "measured in this run: %s" % j.get("source")}
+        return {"conv_bytes": j.get("gru_bytes"), "lookup_bytes": j.get("motion_front_bytes"),
+                "lookup_operator_bytes": j.get("lookup_operator_bytes"), "note": "measured in this run: %s" % j.get("source")}
     except Exception as e:          # counters unavailable on this box: say so, report nothing
         return {"note": "--pmc failed: %s" % (str(e)[:200],)}
 
@@ -166,11 +170,16 @@ def main():
             print("warning: WORLD_SIZE %d != --gpus %d" % (world, args.gpus), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path in the product")
+    if args.dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()          # (ranks may share a device; RCCL needs one device per rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import _synth
     from dkt_stereo_amd import _ffi
@@ -234,11 +243,13 @@ def main():
         sync()
         t1 = time.perf_counter()
         model.check_finite = True
-        if not bool(torch.isfinite(last).all()):
+        gathered_batch = int(last.shape[0]) if last is not None else None      # (rank 0 holds all ranks' maps)
+        if last is not None and not bool(torch.isfinite(last).all()):
             raise SystemExit("bench.py: non-finite disparities in the timed region")
 
         mine = t1 - t0
-        elapsed = torch.tensor([mine], device=dev, dtype=torch.float64)
+        # (gloo carries host tensors; RCCL device tensors)
+        elapsed = torch.tensor([mine], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         per_rank = [mine]
         if world > 1:
             every = [torch.zeros_like(elapsed) for _ in range(world)]
@@ -329,6 +340,20 @@ def main():
                 gru_used.append((sum(d0.x_channels[i] for i in range(d0.nx)), d1.H, d1.W, sum(d1.x_channels[i] for i in range(d1.nx))))
             return ok
 
+        # the launch that carries the lookup inside the loop (dkt_motion_front_c8), timed where the loop runs it: the eager
+        # units keep both streams busy exactly as the captured ones do, and the host runs ahead of the device, so an event
+        # pair on the launch stream brackets the kernel's execution beside the middle GRU's chain
+        real_front = dc8.motion_front
+        front_events = []
+
+        def timed_front(*a, **k):
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            real_front(*a, **k)
+            eb.record()
+            front_events.append((ea, eb))
+
+        dc8.motion_front = timed_front
         dc8.gru_launch = timed_gru
         dc8.launch_pair = timed_pair
         upd.conv2d_gate_zr = timed_gate_zr
@@ -338,6 +363,7 @@ def main():
         model.c8_eager = False
         dc8.launch_pair = real_pair
         dc8.gru_launch = real_gru
+        dc8.motion_front = real_front
         upd.conv2d_gate_zr = real_gate_zr
         dcorr.CorrBlock1D.lookup_conv1x1 = real_fused
         rs.CORR_IMPLEMENTATIONS = real_impls
@@ -355,7 +381,27 @@ def main():
         # pair around an eager launch mostly times the host.  It is therefore timed as the timed region runs it:
         # back-to-back launches replayed from a HIP graph on the launch stream (32 launches per replay, 8
         # replays), on the pyramid and coordinates the timed steps left behind.
+        def graph_time_ms(one, n=32, reps=8):
+            """Average duration of `one()`'s launch: n back-to-back launches per captured graph, `reps` replays."""
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            gl = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gl):
+                for _ in range(n):
+                    one()
+            gl.replay()
+            torch.cuda.synchronize()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            for _ in range(reps):
+                gl.replay()
+            eb.record()
+            torch.cuda.synchronize()
+            return ea.elapsed_time(eb) / (n * reps)
+
         st = model._graph_state
+        front_ms = op_ms = None
         if st is not None:
             blk_, c1_ = st["corr"], st["coords1"]
             layer_ = model.update_block.encoder.convc1
@@ -366,22 +412,29 @@ def main():
                 one = lambda: blk_.lookup_conv1x1(c1_, layer_)          # noqa: E731
             else:
                 one = lambda: blk_(c1_)                                 # noqa: E731
-            for _ in range(3):
-                one()
-            torch.cuda.synchronize()
-            gl = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gl):
-                for _ in range(32):
-                    one()
-            gl.replay()
-            torch.cuda.synchronize()
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ea.record()
-            for _ in range(8):
-                gl.replay()
-            eb.record()
-            torch.cuda.synchronize()
-            look_ms = [ea.elapsed_time(eb) / 256.0] * 256
+            look_ms = [graph_time_ms(one)] * 256
+            # the reference-visible operator corr_fn(coords) (core/corr.py:127-146) on the same pyramid and coordinates
+            op_ms = graph_time_ms(lambda: blk_(c1_))
+            lp0 = st.get("c8")
+            if lp0 is not None and getattr(lp0, "front", False):
+                # the launch the loop makes (dkt_motion_front_c8), stand-alone: the head's planes of the last iteration, the
+                # coordinate buffers alternating as in the loop (two launches per call: the state returns to its parity)
+                fh_, enc_ = model.update_block.flow_head, model.update_block.encoder
+                from dkt_stereo_amd.update import _leading_outputs
+                planes_, nco_ = dc8.head_planes([lp0.hc8[0]], fh_.conv1, _leading_outputs(fh_.conv2, 1), cfg=lp0.cfg["head"])
+                planes_.zero_()            # (delta = bias only: the coordinate stays in range over the 512 timed launches)
+                cx_ = lp0._coords(st)
+                keep_ = [t.clone() for t in (cx_[0], cx_[1], st["flow"])]
+
+                def two_fronts():
+                    for p_ in (0, 1):
+                        real_front(st["corr"], planes_, nco_, None, cx_[p_], cx_[1 - p_], st["coords0"][:, :1], st["flow"],
+                                   enc_.convc1, lp0.cor, enc_.convf1, lp0.flo)
+
+                front_ms = graph_time_ms(two_fronts, n=16) / 2.0
+                for t, k in zip((cx_[0], cx_[1], st["flow"]), keep_):
+                    t.copy_(k)
+        front_pipe_ms = [max(a.elapsed_time(b) - ev_overhead_ms, 1e-6) for a, b in front_events]
         conv_ms = [max(a.elapsed_time(b) - ev_overhead_ms, 1e-6) for a, b in conv_events]
 
         # hot path alone (what the C ABI covers + the update block), encoders excluded
@@ -425,25 +478,25 @@ def main():
     conv_tflops_exec = passes * conv_alg_flops / (conv_avg_ms * 1e-3) / 1e12 if conv_avg_ms > 0 else 0.0
     # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     # rocprofv3 runs of the same kernels on the same shapes); None when the file is absent
+    # The committed passes are quoted ONLY when they profiled the launch timed here: same image size and batch, fused ConvGRU
+    # launch with the same rider (profiles/r05_hbm_traffic[_b<B>].json record both)
     traffic = {}
     try:
-        # round 3's passes measured the C8S kernels (conv_c8_kernel, corr_feat64_kernel); the round-2 kernels' figures
-        # (other conv backends, small images) are in the round-2 file
-        name = "r04_hbm_traffic.json" if gru_used else "r03_hbm_traffic.json" if c8_used else "r02_hbm_traffic.json"
-        if not gru_used and not os.path.exists(os.path.join(ROOT, "profiles", name)):
-            name = "r02_hbm_traffic.json"
-        with open(os.path.join(ROOT, "profiles", name)) as f:
+        with open(os.path.join(ROOT, "profiles", "r05_hbm_traffic%s.json" % ("" if B == 1 else "_b%d" % B))) as f:
             traffic = json.load(f)
     except (OSError, ValueError):
         pass
-    default_shape = (args.height, args.width, B) == (736, 1248, 1)
-    live_traffic = pmc_traffic(args) if (args.pmc and default_shape) else {}
+    default_shape = (args.height, args.width) == (736, 1248) and world == 1
+    traffic_applies = bool(traffic and gru_used and default_shape and traffic.get("shape") == [args.height, args.width, B]
+                           and traffic.get("gru_rider_hw") == [gru_used[0][1], gru_used[0][2]])
+    live_traffic = pmc_traffic(args) if (args.pmc and default_shape and gru_used) else {}
     out = {
         "metric": "stereo pairs/sec at 736x1248 D=192, 32 iters (RAFT-Stereo test_mode forward)",
         "value": world * B * args.steps / elapsed,
         "unit": "pairs/s",
         "n_gpus": world,
         "ranks_seen": ranks_seen,
+        "gathered_batch": gathered_batch,
         "collective_backend": backend,
         "per_rank_pairs_per_s": [B * args.steps / t for t in per_rank],
         "steps": args.steps,
@@ -492,38 +545,59 @@ def main():
                      # launch); otherwise null, and the builder's committed passes are quoted under their own key
                      "traffic": live_traffic.get("conv_bytes"),
                      "traffic_note": live_traffic.get("note", "not measured in this run (pass --pmc)"),
-                     "traffic_from_profiles": ({"bytes": traffic.get("gru_bytes" if gru_used else "conv_zr_gate_bytes"),
+                     "traffic_from_profiles": ({"bytes": traffic.get("gru_bytes"), "compulsory_bytes": traffic.get("gru_compulsory_bytes"),
                                                 "source": "%s -- NOT this run" % traffic.get("source")}
-                                               if default_shape and traffic else None),
+                                               if traffic_applies else None),
                      "algorithmic_flops_per_launch": conv_alg_flops, "mfma_passes": passes,
                      "avg_launch_us": 1e3 * conv_avg_ms, "launches_timed": len(conv_ms),
                      "event_pair_overhead_us": 1e3 * ev_overhead_ms},
-        # the kernel BASELINE.json's north_star sets the HBM target for
-        "roofline_lookup": {"kernel": ("corr_feat64_kernel<4> (dkt_corr1d_lookup_conv1x1%s): pyramid lookup fused with "
-                                       "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA" % ("_c8, C8S output" if (c8_used or gru_used) else "")) if fused_lookup
-                            else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", "bound": "hbm",
-                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": live_traffic.get("lookup_bytes"),
-                            "traffic_note": live_traffic.get("note", "not measured in this run (pass --pmc)"),
-                            "traffic_from_profiles": ({"bytes": traffic.get("lookup_conv1x1_b1_bytes" if fused_lookup else "lookup_b1_bytes"),
-                                                       "source": "%s -- NOT this run" % traffic.get("source")}
-                                                      if default_shape and traffic else None),
-                            "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * look_avg_ms,
-                            "launches_timed": len(look_ms),
-                            # where the loop runs it (this entry times the stand-alone launch of the same lookup + 1x1 layer)
-                            "in_loop": ("since round 4 inside motion_front_kernel (dkt_motion_front_c8: the coordinate update "
-                                        "behind the flow head + this lookup and 1x1 layer + the motion encoder's 7x7 stem, one "
-                                        "launch per iteration; profiles/r04_pair_breakdown.txt)" if front_used else "its own launch"),
-                            # the same kernel as the loop runs it (rocprofv3 kernel trace of this command, kept under profiles/)
-                            "in_pipeline_from_profiles": ({"avg_launch_us": traffic.get("lookup_in_pipeline_us"),
-                                                           "frac": alg / (traffic["lookup_in_pipeline_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                                           "source": "%s -- NOT this run" % traffic.get("lookup_in_pipeline_source")}
-                                                          if default_shape and traffic.get("lookup_in_pipeline_us") else None)},
+        # the kernel BASELINE.json's north_star sets the HBM target for: see lookup_rooflines() below
+        "roofline_lookup": None,
     }
+    # ---- the corr-lookup kernel (HBM-bound; north_star: >= 60 % of HBM), three forms, all timed live in this run:
+    #   (1) what the loop launches: motion_front_kernel (coordinate update + lookup + convc1 + 7x7 stem), stand-alone
+    #       (graph-replayed back to back) AND in the pipeline (event pairs around the loop's own launches, beside the middle
+    #       GRU's chain on the other stream);
+    #   (2) the lookup fused with convc1 alone (corr_feat64_kernel), the round-3 form the front embeds;
+    #   (3) the reference-visible operator corr_fn(coords) (corr1d_lookup_skew_kernel).
+    def hbm(alg_bytes, ms):
+        ach = alg_bytes / (ms * 1e-3) / 1e9 if ms and ms > 0 else 0.0
+        return {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": 1e3 * ms if ms else None}
+
+    alg_op = lookup_bytes_per_launch(n_pix)
+    # front: the fused lookup's 420 B/pixel + the head's 18 planes (72) + old coordinate, reference coordinate (8) read, new
+    # coordinate and flow (8) written + the stem's 64 C8S channels (256) written = 764 B/pixel
+    alg_front = n_pix * (420 + 72 + 8 + 8 + 256)
+    fused_entry = dict(hbm(alg, look_avg_ms), kernel=("corr_feat64_kernel<4> (dkt_corr1d_lookup_conv1x1%s): pyramid lookup fused with "
+                       "the motion encoder's 1x1 layer, 36 -> 64 channels, exact-fp32 MFMA" % ("_c8, C8S output" if (c8_used or gru_used) else ""))
+                       if fused_lookup else "corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew)", launches_timed=len(look_ms))
+    op_entry = (dict(hbm(alg_op, op_ms), kernel="corr1d_lookup_skew_kernel<4> (dkt_corr1d_lookup_skew): the reference-visible "
+                     "CorrBlock1D.__call__ (core/corr.py:127-146), 308 B/pixel", launches_timed=256) if op_ms else None)
+    if front_used and front_ms:
+        pipe_ms = sum(front_pipe_ms) / max(len(front_pipe_ms), 1) if front_pipe_ms else None
+        rl = dict(hbm(alg_front, front_ms), bound="hbm",
+                  kernel="motion_front_kernel<4> (dkt_motion_front_c8): what the loop launches once per iteration -- coordinate update "
+                         "behind the flow head + pyramid lookup + convc1 (36 -> 64, exact-fp32 MFMA) + the motion encoder's 7x7 stem, "
+                         "C8S outputs; 764 B/pixel algorithmic", launches_timed=256,
+                  in_pipeline_avg_launch_us=1e3 * pipe_ms if pipe_ms else None,
+                  in_pipeline_frac=(alg_front / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pipe_ms else None,
+                  in_pipeline_launches_timed=len(front_pipe_ms),
+                  in_pipeline_note="event pairs around the loop's own launches in this run (eager units, both streams busy as in the "
+                                   "captured loop); the launch shares the device with the middle GRU's z|r convolution",
+                  fused_lookup_conv1x1=fused_entry, reference_operator=op_entry)
+    else:
+        rl = dict(fused_entry, bound="hbm", in_loop="its own launch", reference_operator=op_entry)
+    rl["traffic"] = live_traffic.get("lookup_bytes")
+    rl["traffic_note"] = live_traffic.get("note", "not measured in this run (pass --pmc)")
+    rl["traffic_kernel"] = "motion_front_kernel (the loop's launch)"
+    rl["traffic_from_profiles"] = ({"bytes": traffic.get("motion_front_bytes"), "reference_operator_bytes": traffic.get("lookup_operator_bytes"),
+                                    "source": "%s -- NOT this run" % traffic.get("source")}
+                                   if traffic_applies and front_used else None)
+    out["roofline_lookup"] = rl
     # EPE against the reference itself (BASELINE.json's "EPE vs ref"): tests/golden/raft_e2e.npz holds the
     # reference's CPU output for this exact workload (seed 3, shift 40, 32 iterations, every 8th pixel)
-    if default_shape and args.iters == 32:
+    if default_shape and B == 1 and args.iters == 32:
         try:
             import numpy as np
             sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -6,6 +6,7 @@ torch type crosses the ABI.  There is no CPU fallback -- if the library is
 missing or a call fails this module raises.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -205,9 +206,31 @@ def lib():
     return _lib
 
 
+_LAUNCH_LOG = threading.local()
+
+
+class launch_log:
+    """Collects the names of the C-ABI launches this thread makes inside the block (every launch is followed by check()):
+    how the tests and bench.py count the dispatches of a captured loop unit."""
+
+    def __enter__(self):
+        self.prev = getattr(_LAUNCH_LOG, "names", None)
+        self.names = _LAUNCH_LOG.names = []
+        return self.names
+
+    def __exit__(self, *exc):
+        _LAUNCH_LOG.names = self.prev
+        if self.prev is not None:
+            self.prev.extend(self.names)
+        return False
+
+
 def check(rc, what):
     if rc != 0:
         raise DktError("%s failed: %s (rc=%d)" % (what, lib().dkt_strerror(rc).decode(), rc))
+    names = getattr(_LAUNCH_LOG, "names", None)
+    if names is not None:
+        names.append(what)
 
 
 def ptr_array(tensors):

@@ -445,9 +445,10 @@ def stats_eligible(layer):
     return hip_eligible(layer) and _stride_of(layer) in ((1, 1), (2, 2)) and not direct_eligible(layer) and not few_eligible(layer)
 
 
-def conv2d_stats(x, layer, in_norm=None):
+def conv2d_stats(x, layer, in_norm=None, _ws=None):
     """conv(x) + bias with the statistics of its OWN output for the InstanceNorm2d that follows it
-    (core/extractor.py:46-50): returns (out, OutStats).  `in_norm` as in conv2d_fused (stride 1 only)."""
+    (core/extractor.py:46-50): returns (out, OutStats).  `in_norm` as in conv2d_fused (stride 1 only).
+    `_ws`: the per-(tile, wave row) scratch of dkt_conv2d_stats_ws_floats floats, handed in by the guarded-buffer test."""
     op = _Operands(x, layer)
     stride = _stride_of(layer)[0]
     Ho, Wo = (op.H - 1) // stride + 1, (op.W - 1) // stride + 1
@@ -456,7 +457,10 @@ def conv2d_stats(x, layer, in_norm=None):
     d = _desc(op, out)
     d.stride = stride
     planes = op.B * op.cout
-    ws = torch.empty(int(L.dkt_conv2d_stats_ws_floats(op.B, op.cout, Ho, Wo)), device=op.device, dtype=torch.float32)
+    n_ws = int(L.dkt_conv2d_stats_ws_floats(op.B, op.cout, Ho, Wo))
+    ws = torch.empty(n_ws, device=op.device, dtype=torch.float32) if _ws is None else _ws
+    if ws.numel() < n_ws or ws.dtype != torch.float32 or not ws.is_contiguous():
+        raise ValueError("conv2d_stats: scratch of dkt_conv2d_stats_ws_floats floats expected")
     part = torch.empty(int(L.dkt_instance_norm_workspace(planes, Ho * Wo)), device=op.device, dtype=torch.uint8)
     d.stats_ws, d.stats_part = ws.data_ptr(), part.data_ptr()
     keep = (ws, part)

@@ -6,6 +6,7 @@
 (core/update.py:16-32), BasicMotionEncoder (:64-85), FlowHead.conv1 (:9)."""
 import ctypes
 import math
+import threading
 
 import torch
 
@@ -108,14 +109,43 @@ class _PackedC8:
 _PACK_KEEP = 6
 
 
+_PINS = threading.local()
+
+
+class pin_packs:
+    """Every packed image looked up or made on this thread inside the block is appended to `keep` (strong references): a
+    captured graph bakes the images' addresses in, while the per-layer caches evict beyond _PACK_KEEP entries -- the capturing
+    loop holds what its graphs point to until it drops them (another thread's recalibrations could free them)."""
+
+    def __init__(self, keep):
+        self.keep = keep
+
+    def __enter__(self):
+        self.prev = getattr(_PINS, "keep", None)
+        _PINS.keep = self.keep
+        return self.keep
+
+    def __exit__(self, *exc):
+        _PINS.keep = self.prev
+        return False
+
+
+def _pinned(p):
+    keep = getattr(_PINS, "keep", None)
+    if keep is not None and p is not None:
+        keep.append(p)
+    return p
+
+
 def _cache_get(cache, slot, key):
     for p in cache.get(slot, ()):
         if p.key == key:
-            return p
+            return _pinned(p)
     return None
 
 
 def _cache_put(cache, slot, p, n_weight_keys):
+    _pinned(p)
     keep = [q for q in cache.get(slot, ()) if q.key[:n_weight_keys] == p.key[:n_weight_keys]]
     cache[slot] = (keep + [p])[-_PACK_KEEP:]
 

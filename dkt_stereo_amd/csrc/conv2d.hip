@@ -983,7 +983,10 @@ static int conv_width_class(int Cout) { return Cout <= 32 ? 0 : Cout <= 64 ? 1 :
 
 extern "C" long dkt_conv2d_stats_ws_floats(int B, int Cout, int Ho, int Wo) {
     if (B <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0) return DKT_E_SHAPE;
-    return (long)B * ((Wo + 31) / 32) * Ho * Cout * 2;       // at most one entry per output row and 32-column strip
+    // One entry per (tile, wave row): tiles_w * ceil(Ho / TR) * WN per image with TR = WN * NF rows per tile, TR in {1, 2, 4, 8}
+    // over the tile shapes -- waves whose rows lie past Ho write (zero) entries too, so the bound is Ho rounded UP to 8 rows per
+    // 32-column strip (`Ho` entries were 9 short at Ho = 33 on the 4-row shapes)
+    return (long)B * ((Wo + 31) / 32) * ((Ho + 7) / 8 * 8) * Cout * 2;
 }
 
 extern "C" int dkt_conv2d_f16s_desc(const dkt_conv_desc *p, int passes, int device, void *stream) {

@@ -14,6 +14,7 @@ plain loop.  The feature / 3-D aggregation networks that produce the inputs are 
 library.
 """
 import os
+import warnings
 import weakref
 
 import torch
@@ -252,7 +253,16 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
                 dst.copy_(src)
     ub = update_block
     if USE_C8 and loop_c8.eligible_igev(ub, st.net[0].shape):
-        return _iterate_c8(ub, st, iters)
+        out = _iterate_c8(ub, st, iters)
+        if st.c8.take_error():
+            # a fused ConvGRU launch gave up waiting for a neighbour tile (csrc/gru_c8.hip): the result is wrong.
+            # Two-launch form from here on, and this call is computed again from the caller's (untouched) inputs.
+            warnings.warn("dkt_stereo_amd: the fused ConvGRU launch timed out waiting for a neighbour tile; "
+                          "falling back to the two-launch form for this update block (one fused-GRU model per device)")
+            st.c8.disable_fused_gru()
+            return _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph,
+                                 cache if cache is not None else dict(state=st))
+        return out
     if ROTATE and PAIR_GRUS:
         mask = _iterate_rotated(ub, st, iters)
         return st.disp.clone(), mask, [t.clone() for t in st.net]

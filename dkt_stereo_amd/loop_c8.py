@@ -131,6 +131,8 @@ class C8Loop:
         self.graph = None                # [parity] one unit
         self.graph_n = None              # [parity] GRAPH_UNITS units
         self.graph_last = None           # [parity] the final unit of a pair
+        self.pinned = []                 # packed weight images the captured units point to (see capture)
+        self.unit_launches = None
         self.front = bool(FRONT) and self._front_supported(st)
         mask = getattr(ub, "mask", None)               # (IGEV's mask features are computed by its caller)
         self.mask_head = mask if (mask is not None and len(mask) == 3 and isinstance(mask[0], torch.nn.Conv2d)
@@ -152,14 +154,17 @@ class C8Loop:
         torch.cuda.synchronize()
         keep = self.par
         self.graph, self.graph_last, self.graph_n = {}, {}, {}
+        self.pinned = []                 # the packed weight images the captured launches point to (conv_c8.pin_packs)
         for p in ((0, 1) if self.front else (0,)):
             def cap(fn):
                 self.par = p
                 g = torch.cuda.CUDAGraph()
-                with capture_graph(g):
+                with capture_graph(g), c8.pin_packs(self.pinned):
                     fn()
                 return g
-            self.graph[p] = cap(lambda: self.unit(st))
+            with _ffi.launch_log() as names:
+                self.graph[p] = cap(lambda: self.unit(st))
+            self.unit_launches = list(names)          # the dispatches of one captured unit (tests pin their number)
             self.graph_last[p] = cap(lambda: self.unit(st, last=True))
             if GRAPH_UNITS > 1:
                 self.graph_n[p] = cap(lambda: [self.unit(st) for _ in range(GRAPH_UNITS)])
@@ -243,6 +248,24 @@ class C8Loop:
                 break
         self.calibrated = True
         self.graph = self.graph_n = self.graph_last = None     # (a captured unit bakes the scales in)
+        self.pinned = []
+        self.par = 0
+
+    def take_error(self):
+        """True when a fused ConvGRU launch of this loop gave up waiting for a neighbour tile's flag (csrc/gru_c8.hip: the
+        block then continued on stale r*h, so the results since are wrong).  One host synchronisation; the word is cleared, so a
+        later forward is not blamed for this one."""
+        bad = bool(int(self.err.item()))
+        if bad:
+            self.err.zero_()
+        return bad
+
+    def disable_fused_gru(self):
+        """The two-launch form of the finest ConvGRU from here on (after a flag time-out: this device does not keep the
+        launch's blocks resident, e.g. another process holds part of the CUs); captured units are dropped."""
+        self.fuse_gru = False
+        self.graph = self.graph_n = self.graph_last = None
+        self.pinned = []
         self.par = 0
 
     def ranges_ok(self):

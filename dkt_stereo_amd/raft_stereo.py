@@ -16,6 +16,7 @@ correlation block and the update operator as autograd nodes on this library's ke
 """
 import itertools
 import os
+import warnings
 import threading
 import weakref
 from concurrent.futures import ThreadPoolExecutor
@@ -28,7 +29,7 @@ import torch.nn.functional as F
 from . import _ffi
 from .conv import conv2d
 from .corr import CORR_IMPLEMENTATIONS
-from .extractor import BasicEncoder, MultiBasicEncoder
+from .extractor import BasicEncoder, MultiBasicEncoder, ResidualBlock
 from .update import (FUSE_GATES, GPU_GUARD, BasicMultiUpdateBlock, _side_stream, capture_graph, gru_pair, harness, interp,
                      pool2x, replay_graph)
 from . import conv as _conv
@@ -155,9 +156,8 @@ class RAFTStereo(nn.Module):
     def __init__(self, args=None):
         super().__init__()
         self.args = args = args if args is not None else make_args()
-        if args.backbone_type != 'default' or args.shared_backbone:
-            raise NotImplementedError("harness covers the default two-encoder backbone "
-                                      "(configs/raft_stereo/base.json)")
+        if args.backbone_type not in ('default', 'interpolate'):
+            raise ValueError("backbone_type: 'default' or 'interpolate' (raft_stereo.py:43-54)")
         context_dims = args.hidden_dims
         self.cnet = MultiBasicEncoder(output_dim=[args.hidden_dims, context_dims],
                                       norm_fn=args.context_norm, downsample=args.n_downsample)
@@ -165,7 +165,33 @@ class RAFTStereo(nn.Module):
         self.context_zqr_convs = nn.ModuleList(
             [nn.Conv2d(context_dims[i], args.hidden_dims[i] * 3, 3, padding=3 // 2)
              for i in range(args.n_gru_layers)])
-        self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', downsample=args.n_downsample)
+        # raft_stereo.py:43-54: the default two-encoder backbone; `shared_backbone` = the context encoder's trunk on both
+        # images + a residual block and a 3x3 layer (parameters conv2.0.*, conv2.1.*); 'interpolate' = no feature encoder,
+        # the correlation runs on the bilinearly down-sampled images themselves
+        if args.backbone_type == 'default':
+            if args.shared_backbone:
+                self.conv2 = nn.Sequential(ResidualBlock(128, 128, 'instance', stride=1), nn.Conv2d(128, 256, 3, padding=1))
+            else:
+                self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', downsample=args.n_downsample)
+
+    @property
+    def _two_encoders(self):
+        return self.args.backbone_type == 'default' and not self.args.shared_backbone
+
+    def _variant_features(self, image1, image2, n):
+        """(cnet_list, fmap1, fmap2) of the non-default backbones, raft_stereo.py:97-108 (images already normalised)."""
+        if self.args.backbone_type == 'default':                    # shared_backbone
+            *cnet_list, x = self.cnet(torch.cat((image1, image2), dim=0), dual_inp=True, num_layers=n)
+            f = self.conv2[1]
+            y = self.conv2[0](x)
+            y = conv2d(y, f) if (y.is_cuda and not torch.is_grad_enabled()) else f(y)
+            fmap1, fmap2 = y.split(dim=0, split_size=x.shape[0] // 2)
+        else:                                                       # 'interpolate'
+            cnet_list = self.cnet(image1, num_layers=n)
+            dw = 1 / (2 ** self.args.n_downsample)
+            fmap1 = F.interpolate(image1, scale_factor=(dw, dw), mode='bilinear', align_corners=True)
+            fmap2 = F.interpolate(image2, scale_factor=(dw, dw), mode='bilinear', align_corners=True)
+        return list(cnet_list), fmap1.contiguous(), fmap2.contiguous()
 
     #: a replica made by nn.DataParallel runs its test_mode forward on a persistent per-device copy of the master (_Shadow):
     #: captured loop and packed weights survive between forwards.  False: replicas run the plain loop themselves
@@ -192,7 +218,7 @@ class RAFTStereo(nn.Module):
 
     def _encoder_fingerprint(self):
         fp = [(_conv.get_backend(), _extractor.FUSE_ENCODER, self.encoder_streams)]
-        for mod in (self.fnet, self.cnet, self.context_zqr_convs):
+        for mod in ([self.fnet] if self._two_encoders else [m for m in [getattr(self, "conv2", None)] if m is not None]) + [self.cnet, self.context_zqr_convs]:
             for t in list(mod.parameters()) + list(mod.buffers()):
                 fp.append((t.data_ptr(), t._version))
             for m in mod.modules():
@@ -299,6 +325,11 @@ class RAFTStereo(nn.Module):
     def _encode(self, image1, image2):
         image1, image2, both = self._normalized_pair(image1, image2)
         n = self.args.n_gru_layers
+        if not self._two_encoders:
+            self._prebuilt = None
+            cnet_list, fmap1, fmap2 = self._variant_features(image1, image2, n)
+            cnet_list = [self._context_post(i, list(outs)) for i, outs in enumerate(cnet_list)]
+            return fmap1.float(), fmap2.float(), [x[0] for x in cnet_list], [x[1] for x in cnet_list]
         fnet_in = [image1, image2] if both is None else both
         split = lambda f: f if both is None else f.split(split_size=image1.shape[0], dim=0)
         if self.encoder_streams and image1.is_cuda:
@@ -324,10 +355,15 @@ class RAFTStereo(nn.Module):
         """core/corr.py:148-156 + :111-125 for this pair into the captured loop's correlation block, on the feature
         encoder's stream (see prebuild_corr); iterate() finds it done."""
         self._prebuilt = None
+        if torch.is_grad_enabled():
+            return               # (rebuild() under autograd would go through _BuildFn and replace the captured loop's pyramid tensors)
         corr = self._prebuild_target(image1)
         if corr is not None and tuple(fmap1.shape) == tuple(self._graph_state["fmap_shape"]):
-            corr.rebuild(fmap1.float(), fmap2.float())
-            self._prebuilt = corr
+            f1, f2 = fmap1.float(), fmap2.float()
+            corr.rebuild(f1, f2)
+            # the hand-over names the feature maps it was built from: iterate() skips its own rebuild only for THESE (ADVICE r04:
+            # encode(A); encode(B); iterate(fmaps_A) must not run on B's volume)
+            self._prebuilt = (corr, f1.data_ptr(), f2.data_ptr())
 
     def _context_post(self, i, outs):
         """raft_stereo.py:103-106 for scale i: tanh of the hidden head, relu + context_zqr convolution of the context
@@ -661,7 +697,7 @@ class RAFTStereo(nn.Module):
             st["inp"] = [list(c.split(split_size=c.shape[1] // 3, dim=1)) for c in st["ctx"]]
             self._graph_state = st
         else:
-            if prebuilt is not st["corr"]:               # (else: the captured encoder pass has rebuilt it for this pair)
+            if prebuilt != (st["corr"], fmap1.data_ptr(), fmap2.data_ptr()):   # (else: encode() has rebuilt it for this pair)
                 st["corr"].rebuild(fmap1, fmap2)
             st["coords1"].copy_(st["coords0"])
             if (self.adopt_encoder_outputs and static is not None and static[2] is net_list and static[3] is inp_list):
@@ -729,6 +765,7 @@ class RAFTStereo(nn.Module):
         if (self.use_hip_graph and not getattr(self, "_is_replica", False) and not _conv.calibrating() and iters >= 3 and fmap1.is_cuda and args.corr_implementation == "reg"
                 and CORR_IMPLEMENTATIONS["reg"].__name__ == "CorrBlock1D"):
             return self._iterate_graphed(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+        self._prebuilt = self._static_ctx = None       # (the plain loop builds its own volume: nothing of encode()'s hand-over survives it)
         corr_block = CORR_IMPLEMENTATIONS[args.corr_implementation]
         corr_fn = corr_block(fmap1, fmap2, radius=args.corr_radius, num_levels=args.corr_levels)
         b, _, h, w = net_list[0].shape
@@ -767,8 +804,11 @@ class RAFTStereo(nn.Module):
         n = args.n_gru_layers
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
-        cnet_list = self.cnet(image1, num_layers=n)
-        fmap1, fmap2 = self.fnet([image1, image2])
+        if self._two_encoders:
+            cnet_list = self.cnet(image1, num_layers=n)
+            fmap1, fmap2 = self.fnet([image1, image2])
+        else:
+            cnet_list, fmap1, fmap2 = self._variant_features(image1, image2, n)
         net_list = [torch.tanh(x[0]) for x in cnet_list]
         inp_list = [list(_conv.conv2d_autograd(torch.relu(x[1]), conv).split(split_size=conv.out_channels // 3, dim=1))
                     for x, conv in zip(cnet_list, self.context_zqr_convs)]
@@ -820,9 +860,18 @@ class RAFTStereo(nn.Module):
             flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
             finite = (not self.check_finite) or bool(torch.isfinite(flow_up).all())
             lp = (self._graph_state or {}).get("c8") if self.check_finite else None
-            if lp is not None and int(lp.err.item()):
-                raise _ffi.DktError("the fused ConvGRU launch timed out waiting for a neighbour tile (csrc/gru_c8.hip): "
-                                    "the device did not keep the launch's blocks resident; set DKT_C8_FUSE_GRU=0")
+            if lp is not None and lp.take_error():
+                # A fused ConvGRU launch gave up waiting for a neighbour tile (csrc/gru_c8.hip: its blocks were not all
+                # resident -- another process or model on this device): that forward is wrong.  The word is cleared, the
+                # loop takes the two-launch form from here on and the pair is computed again.
+                warnings.warn("dkt_stereo_amd: the fused ConvGRU launch timed out waiting for a neighbour tile; "
+                              "falling back to the two-launch form for this model (one fused-GRU model per device)")
+                lp.disable_fused_gru()
+                fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
+                flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+                finite = bool(torch.isfinite(flow_up).all())
+                if lp.take_error():
+                    raise _ffi.DktError("the ConvGRU launch reported a flag time-out in the two-launch form (csrc/gru_c8.hip)")
             if lp is not None and lp.calibrated and (not finite or not lp.ranges_ok()):
                 # this pair's activations left the window the C8S scales were picked for: pick again, repeat the forward
                 lp.calibrated = False

@@ -43,6 +43,11 @@ def gather_disparity(local, total, dst=None):
     if local.shape[0] < maxb:
         pad = torch.cat([local, local.new_zeros((maxb - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
     pad = pad.contiguous()
+    # gloo moves device tensors for broadcast / all_reduce only: its gather of device results is staged through the host
+    # (bench.py --dist-backend gloo: two ranks sharing one device in the GPU suite; RCCL takes the device tensors as they are)
+    staged = pad.is_cuda and dist.get_backend() == "gloo"
+    if staged:
+        pad = pad.cpu()
     if dst is None:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad)
@@ -51,4 +56,5 @@ def gather_disparity(local, total, dst=None):
         dist.gather(pad, bufs, dst=dst)
         if rank != dst:
             return None
-    return torch.cat([bufs[r][:hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    full = torch.cat([bufs[r][:hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    return full.to(local.device) if staged else full

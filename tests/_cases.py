@@ -175,6 +175,13 @@ E2E_SLOWFAST_CASES = {
     "sf2_64x128_it6": dict(seed=5, B=1, H=64, W=128, iters=6, shift=12, n=2),
 }
 
+# the non-default backbones of raft_stereo.py:43-54, 97-108 (round 5): the context encoder's trunk shared by both images,
+# and the correlation on the down-sampled images themselves (3 feature channels)
+E2E_BACKBONE_CASES = {
+    "shared_64x128_it6":      dict(seed=6, B=1, H=64, W=128, iters=6, shift=12, over=dict(shared_backbone=True)),
+    "interpolate_64x128_it6": dict(seed=8, B=2, H=64, W=128, iters=6, shift=12, over=dict(backbone_type="interpolate")),
+}
+
 IGEV_LOOP_CASES = {
     "small": dict(seed=71, B=1, Cm=24, C=8, D=16, H=8, W=16, iters=3, n=3, slow_fast=False, stride=1),
     # slow-fast schedule of igev_stereo.py:204-207, 3 and 2 GRU layers

@@ -436,6 +436,25 @@ def gen_e2e(ref):
 
 
 @torch.no_grad()
+def gen_backbones(ref):
+    print("RAFT-Stereo end to end, shared_backbone / backbone_type='interpolate' (raft_stereo.py:43-54, 97-108)")
+    cfg = json.load(open(os.path.join(_refimport.REF, "configs", "raft_stereo", "base.json")))
+    out = {}
+    for name, c in _cases.E2E_BACKBONE_CASES.items():
+        m = ref.RAFTStereo(SimpleNamespace(mixed_precision=False, **{**cfg, **c["over"]}))
+        sd = _synth.torch_state_dict(_synth.shapes_of(m), _cases.E2E_WEIGHT_SEED)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+        flow_lo, flow_up = m(T(i1), T(i2), iters=c["iters"], test_mode=True)
+        out["%s/flow_up" % name] = flow_up.numpy()
+        out["%s/flow_lo" % name] = flow_lo.numpy()[:, :1].copy()
+        MANIFEST["raft_state_dict[%s]" % name] = {k: list(v) for k, v in sorted(_synth.shapes_of(m).items())}
+        print("   %s: disparity range %.2f .. %.2f" % (name, float(-flow_up.max()), float(-flow_up.min())))
+    save("raft_backbones", **out)
+
+
+@torch.no_grad()
 def gen_igev_loop(ref):
     print("IGEV GRU loop from match features onward")
     out = {}
@@ -542,7 +561,7 @@ def main():
     ref = _refimport.load()
     only = set(sys.argv[1:])
     gens = [("sampler", gen_sampler), ("corr", gen_corr), ("geo", gen_geo), ("volumes", gen_volumes), ("pcv", gen_pcv), ("corr_bwd", gen_corr_bwd), ("geo_bwd", gen_geo_bwd), ("upsample", gen_upsample), ("files", gen_files),
-            ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e), ("gwcnet", gen_gwcnet), ("eval", gen_eval)]
+            ("gru", gen_gru), ("update", gen_update), ("igev_loop", gen_igev_loop), ("e2e", gen_e2e), ("backbones", gen_backbones), ("gwcnet", gen_gwcnet), ("eval", gen_eval)]
     for name, fn in gens:
         if not only or name in only:
             fn(ref)

@@ -1,0 +1,179 @@
+"""-m gpu: round 5.
+
+* tests that pin the PATH, not only the numbers: at the benchmark workload the loop must be the fused
+  ConvGRU launch + the fused motion front with its error word clear and 9 dispatches per captured unit; the same at batch 8
+  (BASELINE cfg4's per-GPU share) and for IGEV's loop; a declined fused launch gives the two-launch result bit for bit;
+* the instance-norm statistics scratch is not overrun for heights off the tile grid;
+* the non-default backbones of raft_stereo.py:43-54 against reference fixtures;
+* bench.py's N > 1 branch, two ranks sharing this device over gloo.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import _cases
+import _synth
+from test_gpu_parity import DEV, G, _raft, maxabs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+#: the dispatches of one captured RAFT unit (loop_c8.C8Loop.unit): fused ConvGRU step, head conv1 (+ folded conv2), motion front,
+#: convc2 | convf2, encoder.conv on the main queue; pool | interp, gru16 z|r, gru16 q, interp | pool on the forked one
+UNIT_LAUNCHES = ["dkt_gru_c8", "dkt_conv2d_c8", "dkt_motion_front_c8", "dkt_resample_pair_c8", "dkt_conv2d_c8", "dkt_conv2d_c8",
+                 "dkt_resample_pair_c8", "dkt_conv2d_c8_pair", "dkt_conv2d_c8"]
+
+
+def _assert_fast_path(lp, what):
+    assert lp is not None, what + ": the C8S loop did not run"
+    assert lp.fuse_gru, what + ": the fused ConvGRU launch was declined (two-launch form ran)"
+    assert lp.front, what + ": the fused motion front did not run"
+    assert not lp.take_error(), what + ": a fused ConvGRU launch timed out on a neighbour flag"
+    assert lp.unit_launches is not None and sorted(lp.unit_launches) == sorted(UNIT_LAUNCHES), \
+        what + ": a captured unit is %r" % (lp.unit_launches,)
+
+
+@torch.no_grad()
+def test_benchmark_workload_runs_the_fast_path(golden):
+    """736x1248 / 32 iterations, batch 1: fused ConvGRU launch, fused front, error word clear, 9 dispatches per unit -- and the
+    fixture bound through exactly that path."""
+    c = _cases.E2E_CASES["736x1248_it32"]
+    model, _ = _raft()
+    i1, i2 = (G(t) for t in _synth.image_pair(c["seed"], 1, c["H"], c["W"], c["shift"]))
+    model(i1, i2, iters=c["iters"], test_mode=True)
+    _, up = model(i1, i2, iters=c["iters"], test_mode=True)
+    _assert_fast_path(model._graph_state.get("c8"), "B=1")
+    g = golden("raft_e2e")
+    s = int(g["736x1248_it32/stride"])
+    assert maxabs(up[:, :, ::s, ::s], g["736x1248_it32/flow_up"]) <= 1e-3
+
+
+@torch.no_grad()
+def test_batch8_share_runs_the_fast_path():
+    """BASELINE cfg4's per-GPU share (8 pairs per launch): the same path, every block several tiles."""
+    model, _ = _raft()
+    pairs = [_synth.image_pair(1000 + j, 1, 736, 1248, 12 if j % 2 == 0 else 40) for j in range(8)]
+    i1 = torch.cat([torch.from_numpy(p[0]) for p in pairs]).to(DEV)
+    i2 = torch.cat([torch.from_numpy(p[1]) for p in pairs]).to(DEV)
+    model(i1, i2, iters=4, test_mode=True)
+    _, up = model(i1, i2, iters=4, test_mode=True)
+    assert bool(torch.isfinite(up).all())
+    _assert_fast_path(model._graph_state.get("c8"), "B=8")
+
+
+@torch.no_grad()
+def test_igev_loop_runs_the_fused_gru_launch():
+    from test_gpu_round2 import _igev_setup
+    from dkt_stereo_amd import igev_loop
+    c = _cases.IGEV_LOOP_CASES["kitti"]
+    blk, geo_fn, d0, coords, net, inp, _ = _igev_setup(c)
+    cache = {}
+    for _ in range(2):
+        igev_loop.igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, 4, cache=cache)
+    lp = cache["state"].c8
+    assert lp.fuse_gru and not lp.take_error()
+    assert lp.unit_launches is not None and lp.unit_launches.count("dkt_gru_c8") == 1 and len(lp.unit_launches) <= 11, lp.unit_launches
+
+
+@torch.no_grad()
+def test_declined_fused_launch_equals_two_launch_form(monkeypatch):
+    """dkt_gru_c8_pair answering DKT_E_UNSUPPORTED (a device that cannot hold the launch) must leave exactly the two-launch
+    loop: same bits as DKT_C8_FUSE_GRU=0, and the loop object says which form ran."""
+    from dkt_stereo_amd import conv_c8, loop_c8
+    H, W = 544, 960                      # 136 x 240 at 1/4 resolution: 136 tiles >= FUSE_GRU_MIN_TILES
+    i1, i2 = (G(t) for t in _synth.image_pair(5, 1, H, W, 12))
+    monkeypatch.setattr(loop_c8, "FUSE_GRU", False)
+    m0, _ = _raft()
+    _, want = m0(i1, i2, iters=5, test_mode=True)
+    assert not m0._graph_state["c8"].fuse_gru
+    monkeypatch.setattr(loop_c8, "FUSE_GRU", True)
+    monkeypatch.setattr(conv_c8, "gru_launch", lambda *a, **k: False)
+    m1, _ = _raft()
+    _, got = m1(i1, i2, iters=5, test_mode=True)
+    lp = m1._graph_state["c8"]
+    assert not lp.fuse_gru and "dkt_gru_c8" not in lp.unit_launches
+    assert torch.equal(got, want)
+    _, again = m1(i1, i2, iters=5, test_mode=True)
+    assert torch.equal(again, want)
+
+
+@torch.no_grad()
+def test_flag_timeout_falls_back_and_recomputes(monkeypatch):
+    """A raised error word (a fused launch that gave up on a neighbour flag) must not surface as a wrong disparity: forward
+    warns, clears the word, takes the two-launch form and computes the pair again."""
+    H, W = 544, 960
+    i1, i2 = (G(t) for t in _synth.image_pair(6, 1, H, W, 12))
+    model, _ = _raft()
+    _, first = model(i1, i2, iters=4, test_mode=True)
+    lp = model._graph_state["c8"]
+    assert lp.fuse_gru
+    lp.err.fill_(1)
+    with pytest.warns(UserWarning, match="timed out"):
+        _, second = model(i1, i2, iters=4, test_mode=True)
+    assert not lp.fuse_gru and int(lp.err.item()) == 0
+    assert maxabs(second, first) <= 2e-4                     # the other summation order of the two-launch form
+    _, third = model(i1, i2, iters=4, test_mode=True)        # no warning, same path
+    assert torch.equal(third, second)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 40, 33, 70, 1, 3), (2, 64, 64, 37, 45, 1, 3), (1, 64, 96, 75, 90, 2, 3), (2, 48, 96, 21, 64, 1, 3),
+                                   (1, 64, 96, 66, 50, 2, 1)])
+def test_conv_statistics_scratch_is_not_overrun(shape):
+    """dkt_conv2d_stats_ws_floats must cover the entries of waves whose rows lie past Ho (heights off the 4 / 8-row tile grid):
+    the scratch sits in front of a guard area that must keep its pattern."""
+    from dkt_stereo_amd import _ffi, conv
+    B, cin, cout, H, W, stride, k = shape
+    torch.manual_seed(H)
+    layer = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2).to(DEV)
+    x = torch.randn(B, cin, H, W, device=DEV)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    n = int(_ffi.lib().dkt_conv2d_stats_ws_floats(B, cout, Ho, Wo))
+    guard = torch.full((n + 65536,), -12345.0, device=DEV)
+    with conv.use_backend("f16x3"):
+        if not conv.stats_eligible(layer):
+            pytest.skip("layer not on the statistics epilogue")
+        conv.conv2d_stats(x, layer, _ws=guard[:n])
+    torch.cuda.synchronize()
+    assert bool((guard[n:] == -12345.0).all()), "the statistics epilogue wrote past dkt_conv2d_stats_ws_floats"
+
+
+@pytest.mark.parametrize("name", list(_cases.E2E_BACKBONE_CASES))
+@torch.no_grad()
+def test_raft_backbone_variants(name, golden):
+    """shared_backbone / backbone_type='interpolate' (raft_stereo.py:43-54, 97-108) against the reference's own outputs."""
+    c = _cases.E2E_BACKBONE_CASES[name]
+    model, _ = _raft(**c["over"])
+    i1, i2 = _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"])
+    lo, up = model(G(i1), G(i2), iters=c["iters"], test_mode=True)
+    g = golden("raft_backbones")
+    d_up, d_lo = maxabs(up, g[name + "/flow_up"]), maxabs(lo[:, :1], g[name + "/flow_lo"])
+    print("%s: max|d_up| %.3e max|d_lo| %.3e" % (name, d_up, d_lo))
+    assert d_up <= 1e-3 and d_lo <= 1e-3
+
+
+def test_bench_two_ranks_over_gloo_on_one_device(tmp_path):
+    """bench.py's world > 1 branch: two ranks (both on device 0, gloo) -- per-rank timing gather, result gather to rank 0, the
+    rank != 0 early return, one JSON line from rank 0."""
+    from test_dist_cpu import _free_port
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--height", "64",
+                                       "--width", "128", "--iters", "4", "--steps", "2", "--warmup", "1", "--batch", "2", "--skip-cpu-baseline"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["collective_backend"] == "gloo"
+    assert len(j["per_rank_pairs_per_s"]) == 2 and all(v > 0 for v in j["per_rank_pairs_per_s"])
+    assert j["config"]["per_gpu_batch"] == 2 and j["gathered_batch"] == 4
+    assert abs(j["value"] - 2 * 2 * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"])) <= 1e-6 * j["value"]
