@@ -47,7 +47,7 @@ class ConvC8Desc(ctypes.Structure):
                 ("out2_c8", ctypes.c_void_p), ("out2_c8_bstride", ctypes.c_long), ("out2_c8_ch0", ctypes.c_int),
                 ("tail", ctypes.c_void_p), ("tail_bstride", ctypes.c_long), ("tail_channels", ctypes.c_int),
                 ("head_w", ctypes.c_void_p), ("head_out", ctypes.c_void_p), ("head_out_bstride", ctypes.c_long),
-                ("head_outputs", ctypes.c_int), ("f32_c4", ctypes.c_int), ("tail_scale", ctypes.c_float)]
+                ("head_outputs", ctypes.c_int), ("f32_c4", ctypes.c_int), ("tail_scale", ctypes.c_float), ("passes", ctypes.c_int)]
 
 
 class GruC8Desc(ctypes.Structure):
@@ -62,7 +62,7 @@ class GruC8Desc(ctypes.Structure):
                 ("h", ctypes.c_void_p), ("h_bstride", ctypes.c_long),
                 ("scale_zr", ctypes.c_float), ("scale_q", ctypes.c_float), ("act_scale", ctypes.c_float),
                 ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("hidden", ctypes.c_int),
-                ("flags", ctypes.c_void_p)]
+                ("flags", ctypes.c_void_p), ("passes", ctypes.c_int)]
 
 
 class MotionFrontDesc(ctypes.Structure):

@@ -110,6 +110,32 @@ _PACK_KEEP = 6
 
 
 _PINS = threading.local()
+_PASSES = threading.local()
+
+
+class passes:
+    """fp16 MFMA products per weight x activation block of the convolutions described inside the block (this thread):
+    3 = fp32-class (default, the parity path), 2 = activations rounded to fp16, 1 = weights and activations rounded to fp16
+    (dkt_conv_c8_desc.passes / dkt_gru_c8_desc.passes).  Reduced passes are what loop_c8's precision schedules run their
+    early iterations on; nothing else takes them."""
+
+    def __init__(self, n):
+        if n not in (1, 2, 3):
+            raise ValueError("passes: 1, 2 or 3")
+        self.n = n
+
+    def __enter__(self):
+        self.prev = getattr(_PASSES, "n", 3)
+        _PASSES.n = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _PASSES.n = self.prev
+        return False
+
+
+def current_passes():
+    return getattr(_PASSES, "n", 3)
 
 
 class pin_packs:
@@ -287,6 +313,7 @@ def gru_desc(gru, h_c8, xs, rh_c8, cz, cr, cq, h, flags):
     d.scale_zr, d.scale_q, d.act_scale = pk.inv_zr, pk.inv_q, h_c8.scale      # (operand scales live in the packed weights)
     d.B, d.H, d.W, d.hidden = h_c8.B, h_c8.H, h_c8.W, 128
     d.flags = flags.data_ptr()
+    d.passes = current_passes()
     d._keep = (h_c8, xs, rh_c8, pk, cz, cr, cq, h, flags)
     return d
 
@@ -363,6 +390,9 @@ def desc(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, epilogue=
     if tail is not None:
         d.tail_channels = int(tail.shape[1])
     d.f32_c4 = int(bool(f32_c4))
+    d.passes = current_passes()
+    if d.passes == 1 and sum((s.C + 15) // 16 for s in srcs) % 2:
+        d.passes = 2                         # (the one-pass kernel walks its 16-channel chunks in pairs)
     if head_w is not None:
         d.head_w, d.head_out, d.head_out_bstride, d.head_outputs = head_w.data_ptr(), head_out.data_ptr(), head_out.stride(0), int(head_w.shape[0])
     d._keep = (srcs, pk, out, out_c8, e0, e1, h, out2, out2_c8, tail, head_w, head_out)
@@ -375,6 +405,7 @@ def launch(d, ref, cfg=0):
 
 
 def launch_pair(d0, d1, ref, cfg):
+    d0.passes = d1.passes = max(d0.passes, d1.passes)          # (one instantiation runs both problems)
     rc = _ffi.lib().dkt_conv2d_c8_pair(ctypes.byref(d0), ctypes.byref(d1), cfg, _ffi.device_of(ref), _ffi.stream_of(ref))
     _ffi.check(rc, "dkt_conv2d_c8_pair")
 

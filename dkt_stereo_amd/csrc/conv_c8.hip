@@ -101,8 +101,13 @@ __device__ __forceinline__ void c8_wait_lgkm() {
 // WM x WN waves along (output channels, rows); wave tile 64 co x NF rows x 32 columns.
 // RING = weight ring slots: step s computes from slot s % RING while the images of steps s+1 .. s+RING-1 are in the ring or
 // on their way (short steps -- small wave tiles -- need the deeper rings to cover the DMA latency).
-template <int WM, int WN, int NF, int RING>
+// PASSES (round 5): 3 = the fp32-class product above; 2 = w_hi*x_hi + w_lo*x_hi (activations rounded to fp16: their lo planes are
+// never read); 1 = w_hi*x_hi only (plain fp16 operands).  Reduced-pass launches are NOT parity paths by themselves: they serve the
+// precision schedules of loop_c8 (early refinement iterations at fewer passes).  The DMA stream, the ring and the
+// vmcnt waits are the same in all three; what changes is which fragments are read and multiplied (and the lgkmcnt counts).
+template <int WM, int WN, int NF, int RING, int PASSES = 3>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_kernel(C8ArgsPair ap, int nb0) {
+    static_assert(PASSES >= 1 && PASSES <= 3, "passes");
     constexpr int C8_RING = RING;
     constexpr int NW = WM * WN;
     constexpr int TR = WN * NF;                      // output rows per block
@@ -471,33 +476,45 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
     }
     c8_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    // fragments of step 0 that the steps do not fetch themselves: Alo, rows 0 .. NF-1 (in the order the waits count)
-    C8_RD(Alo[0], 2048, lds_w_addr) C8_RD(Alo[1], 2048 + 512, lds_w_addr)
-    C8_RD(Bhi[0], C8_ROW(0, 0, 0), lds_b_addr)
-    if constexpr (NF > 1) C8_RD(Bhi[1], C8_ROW(1, 0, 0), lds_b_addr)
-    if constexpr (NF > 2) C8_RD(Bhi[2], C8_ROW(2, 0, 0), lds_b_addr)
-    if constexpr (NF > 3) C8_RD(Bhi[3], C8_ROW(3, 0, 0), lds_b_addr)
-    C8_RDL(Blo[0], C8_ROW(0, 0, NPP * 16), lds_b_addr)
-    if constexpr (NF > 1) C8_RDL(Blo[1], C8_ROW(1, 0, NPP * 16), lds_b_addr)
-    if constexpr (NF > 2) C8_RDL(Blo[2], C8_ROW(2, 0, NPP * 16), lds_b_addr)
-    if constexpr (NF > 3) C8_RDL(Blo[3], C8_ROW(3, 0, NPP * 16), lds_b_addr)
-    c8_wait_lgkm<0>();
+    // fragments of step 0 that the steps do not fetch themselves: Alo, rows 0 .. NF-1 (in the order the waits count).
+    // PASSES == 1 keeps the A fragments double-buffered in the registers the other forms call Ahi / Alo: a chunk has nine steps,
+    // so a tile's even chunks start from Ahi and its odd ones from Alo -- the chunk loop runs two chunks per trip (the host
+    // refuses odd chunk counts at one pass; a run-time choice between the two step sequences sent the accumulators to scratch).
+    // C8_PRIME(g_) fetches the first step's fragments of a tile from ring slot `sl` / activation buffer g_ & 1.
+#define C8_PRIME(g_)                                                                                        \
+    {                                                                                                       \
+        const unsigned aw = lds_w_addr + sl * WSLOT, ab = lds_b_addr + ((g_) & 1) * ACT_BYTES;              \
+        if constexpr (PASSES == 1) { C8_RD(Ahi[0], 0, aw) C8_RD(Ahi[1], 512, aw) }                         \
+        else { C8_RD(Alo[0], 2048, aw) C8_RD(Alo[1], 2048 + 512, aw) }                                      \
+        C8_RD(Bhi[0], C8_ROW(0, 0, 0), ab)                                                                  \
+        if constexpr (NF > 1) C8_RD(Bhi[1], C8_ROW(1, 0, 0), ab)                                            \
+        if constexpr (NF > 2) C8_RD(Bhi[2], C8_ROW(2, 0, 0), ab)                                            \
+        if constexpr (NF > 3) C8_RD(Bhi[3], C8_ROW(3, 0, 0), ab)                                            \
+        if constexpr (PASSES == 3) {                                                                        \
+            C8_RDL(Blo[0], C8_ROW(0, 0, NPP * 16), ab)                                                      \
+            if constexpr (NF > 1) C8_RDL(Blo[1], C8_ROW(1, 0, NPP * 16), ab)                                \
+            if constexpr (NF > 2) C8_RDL(Blo[2], C8_ROW(2, 0, NPP * 16), ab)                                \
+            if constexpr (NF > 3) C8_RDL(Blo[3], C8_ROW(3, 0, NPP * 16), ab)                                \
+        }                                                                                                   \
+        c8_wait_lgkm<0>();                                                                                  \
+    }
     int g = 0;              // chunks consumed by this block: activation buffer parity
     int sl = 0;             // ring slot of the step being computed
+    C8_PRIME(0)
     for (;;) {
         const int tn = tile + blk_count;
         const bool have_next = tn < a.total_tiles;
         int nh0 = h0, nw0 = w0, nco = co_blk, nb = b;
         if (have_next) decode(tn, nh0, nw0, nco, nb);
-        for (int c = 0; c < a.nchunks; ++c, ++g) {
-            const bool in_tile = c + 1 < a.nchunks;
-            // the chunk that follows in this block's stream: this tile's next one, else the next tile's first,
-            // else (the block's very last chunk) this one again, harmlessly
-            const int c_f = in_tile ? c + 1 : (have_next ? 0 : c);
-            const char *w_next = w_tile(have_next ? nco : co_blk);
-            const int b_f = in_tile ? b : nb;
-            if (!in_tile && have_next) tile_offsets(nh0, nw0, aoff_nxt);
-            const char *act_f = chunk_base(b_f, c_f);
+#define C8_CHUNK_SETUP(c)                                                                                     \
+            const bool in_tile = (c) + 1 < a.nchunks;                                                             \
+            /* the chunk that follows in this block's stream: this tile's next one, else the next tile's first, */ \
+            /* else (the block's very last chunk) this one again, harmlessly */                                   \
+            const int c_f = in_tile ? (c) + 1 : (have_next ? 0 : (c));                                            \
+            const char *w_next = w_tile(have_next ? nco : co_blk);                                                \
+            const int b_f = in_tile ? b : nb;                                                                     \
+            if (!in_tile && have_next) tile_offsets(nh0, nw0, aoff_nxt);                                          \
+            const char *act_f = chunk_base(b_f, c_f);                                                             \
             const int cur = g & 1, nxt = cur ^ 1;
             // One (chunk, tap) step.  Steps run tap COLUMN by column (dx outer, dy inner: the weight images are packed in
             // that order), so that a B fragment -- one patch row r at column dx -- serves the (up to) three steps dy = r - n:
@@ -572,7 +589,103 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         if constexpr (NF > 3) { C8_MM(Ahi, 0, Blo, 3 + DY, 3) C8_MM(Ahi, 1, Blo, 3 + DY, 3) }                                \
         sl = sl1;                                                                                                      \
     }
-            C8_STEP(0) C8_STEP(1) C8_STEP(2) C8_STEP(3) C8_STEP(4) C8_STEP(5) C8_STEP(6) C8_STEP(7) C8_STEP(8)
+            // ---- the step's shared head (waits for this step's DMA, barrier) and DMA issue, as in C8_STEP
+#define C8_STEP_HEAD(T)                                                                                                \
+        constexpr int DX = (T) / 3, DY = (T) % 3, NDX = (DX + 1) % 3;                                                  \
+        const int sl1 = sl + 1 == C8_RING ? 0 : sl + 1, sl2 = sl == 0 ? C8_RING - 1 : sl - 1;                         \
+        const unsigned adw_s = lds_w_addr + sl * WSLOT;                                                                \
+        const unsigned adw_n = lds_w_addr + sl1 * WSLOT;                                                               \
+        const unsigned adb_c = lds_b_addr + cur * ACT_BYTES;                                                           \
+        const unsigned adb_n = lds_b_addr + (DX < 2 ? cur : nxt) * ACT_BYTES;                                          \
+        (void)adw_s; (void)adw_n; (void)adb_c; (void)adb_n;                                                            \
+        if ((T) >= 1 && (T) <= C8_RING - 3) c8_wait_vm<(C8_RING - 3) * WPI + NIA>();                                   \
+        else c8_wait_vm<(C8_RING - 3) * WPI>();                                                                        \
+        __builtin_amdgcn_s_barrier();
+#define C8_STEP_DMA(T)                                                                                                 \
+        if ((T) == 10 - C8_RING && !in_tile) wptr = w_next;                                                            \
+        if ((T) == 0) {                                                                                                \
+            if (in_tile || !have_next) issue_act(act_f, aoff_cur, nxt);                                                \
+            else issue_act(act_f, aoff_nxt, nxt);                                                                      \
+        }                                                                                                              \
+        issue_w(wptr, sl2);                                                                                            \
+        wptr += wstep;                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);
+            // PASSES == 2: C8_STEP without its Z pass and without any lo row.  LDS reads in issue order:
+            //   X (Alo x Bhi): Ahi[0], Ahi[1]; dy = 0: row NF; dy = 1: row NF+1
+            //   Y (Ahi x Bhi): Alo'[0], Alo'[1], then the dying rows (for the next column)
+            // so a step starts with its Alo and rows in once at most the previous step's dying-row reads fly (1 after dy = 0,
+            // 1 after dy = 1 when NF > 1, none after dy = 2: the rows re-read there are this step's)
+#define C8_STEP2(T)                                                                                                    \
+    {                                                                                                                  \
+        C8_STEP_HEAD(T)                                                                                                \
+        if constexpr (DY == 1) c8_wait_lgkm<1>();                                                                      \
+        else if constexpr (DY == 2) c8_wait_lgkm<(NF > 1 ? 1 : 0)>();                                                  \
+        else c8_wait_lgkm<0>();                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        C8_MM(Alo, 0, Bhi, DY, 0) C8_RD(Ahi[0], 0, adw_s)                                                              \
+        C8_MM(Alo, 1, Bhi, DY, 0) C8_RD(Ahi[1], 512, adw_s)                                                            \
+        if constexpr (NF > 1) { C8_MM(Alo, 0, Bhi, 1 + DY, 1)                                                          \
+            if constexpr (DY < 2) C8_RD(Bhi[NF + DY], C8_ROW(NF + DY, DX, 0), adb_c)                                   \
+            C8_MM(Alo, 1, Bhi, 1 + DY, 1) }                                                                            \
+        else if constexpr (DY < 2) C8_RD(Bhi[NF + DY], C8_ROW(NF + DY, DX, 0), adb_c)                                  \
+        if constexpr (NF > 2) { C8_MM(Alo, 0, Bhi, 2 + DY, 2) C8_MM(Alo, 1, Bhi, 2 + DY, 2) }                          \
+        if constexpr (NF > 3) { C8_MM(Alo, 0, Bhi, 3 + DY, 3) C8_MM(Alo, 1, Bhi, 3 + DY, 3) }                          \
+        C8_STEP_DMA(T)                                                                                                 \
+        c8_wait_lgkm<(DY < 2 ? 1 : 0)>(); /* Ahi is in (the row read ahead may still fly) */                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        C8_MM(Ahi, 0, Bhi, DY, 0) C8_RD(Alo[0], 2048, adw_n)                                                           \
+        C8_MM(Ahi, 1, Bhi, DY, 0) C8_RD(Alo[1], 2048 + 512, adw_n)                                                     \
+        if constexpr (DY == 0) C8_RD(Bhi[0], C8_ROW(0, NDX, 0), adb_n)                                                 \
+        if constexpr (DY == 1 && NF > 1) C8_RD(Bhi[1], C8_ROW(1, NDX, 0), adb_n)                                       \
+        if constexpr (DY == 2 && NF > 2) C8_RD(Bhi[2], C8_ROW(2, NDX, 0), adb_n)                                       \
+        if constexpr (NF > 1) { C8_MM(Ahi, 0, Bhi, 1 + DY, 1) C8_MM(Ahi, 1, Bhi, 1 + DY, 1)                            \
+            if constexpr (DY == 2 && NF > 3) C8_RD(Bhi[3], C8_ROW(3, NDX, 0), adb_n) }                                 \
+        if constexpr (NF > 2) { C8_MM(Ahi, 0, Bhi, 2 + DY, 2) C8_MM(Ahi, 1, Bhi, 2 + DY, 2) }                          \
+        if constexpr (NF > 3) { C8_MM(Ahi, 0, Bhi, 3 + DY, 3) C8_MM(Ahi, 1, Bhi, 3 + DY, 3) }                          \
+        sl = sl1;                                                                                                      \
+    }
+            // PASSES == 1: one product per block, A fragments double-buffered (PA: this step's, PB: the next step's, fetched first
+            // thing behind the barrier), MFMAs row by row so that a dying row is re-read as soon as its last product has issued.
+            // LDS reads in issue order: PB[0], PB[1]; dy < 2: row NF + dy; then the dying rows.  Waits as in C8_STEP2.
+#define C8_STEP1(T, PA, PB)                                                                                            \
+    {                                                                                                                  \
+        C8_STEP_HEAD(T)                                                                                                \
+        if constexpr (DY == 1) c8_wait_lgkm<1>();                                                                      \
+        else if constexpr (DY == 2) c8_wait_lgkm<(NF > 1 ? 1 : 0)>();                                                  \
+        else c8_wait_lgkm<0>();                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        C8_RD(PB[0], 0, adw_n) C8_RD(PB[1], 512, adw_n)                                                                \
+        if constexpr (DY < 2) C8_RD(Bhi[NF + DY], C8_ROW(NF + DY, DX, 0), adb_c)                                       \
+        C8_MM(PA, 0, Bhi, DY, 0) C8_MM(PA, 1, Bhi, DY, 0)                                                              \
+        if constexpr (DY == 0) C8_RD(Bhi[0], C8_ROW(0, NDX, 0), adb_n)                                                 \
+        if constexpr (DY == 1 && NF > 1) C8_RD(Bhi[1], C8_ROW(1, NDX, 0), adb_n)                                       \
+        if constexpr (DY == 2 && NF > 2) C8_RD(Bhi[2], C8_ROW(2, NDX, 0), adb_n)                                       \
+        C8_STEP_DMA(T)                                                                                                 \
+        if constexpr (NF > 1) { C8_MM(PA, 0, Bhi, 1 + DY, 1) C8_MM(PA, 1, Bhi, 1 + DY, 1)                              \
+            if constexpr (DY == 2 && NF > 3) C8_RD(Bhi[3], C8_ROW(3, NDX, 0), adb_n) }                                 \
+        if constexpr (NF > 2) { C8_MM(PA, 0, Bhi, 2 + DY, 2) C8_MM(PA, 1, Bhi, 2 + DY, 2) }                            \
+        if constexpr (NF > 3) { C8_MM(PA, 0, Bhi, 3 + DY, 3) C8_MM(PA, 1, Bhi, 3 + DY, 3) }                            \
+        sl = sl1;                                                                                                      \
+    }
+#define C8_CHUNK1(PA, PB)                                                                                     \
+            C8_STEP1(0, PA, PB) C8_STEP1(1, PB, PA) C8_STEP1(2, PA, PB) C8_STEP1(3, PB, PA) C8_STEP1(4, PA, PB)   \
+            C8_STEP1(5, PB, PA) C8_STEP1(6, PA, PB) C8_STEP1(7, PB, PA) C8_STEP1(8, PA, PB)
+        if constexpr (PASSES == 1) {
+            for (int c = 0; c < a.nchunks; c += 2) {
+                { C8_CHUNK_SETUP(c) C8_CHUNK1(Ahi, Alo) }
+                ++g;
+                { C8_CHUNK_SETUP(c + 1) C8_CHUNK1(Alo, Ahi) }
+                ++g;
+            }
+        } else {
+            for (int c = 0; c < a.nchunks; ++c, ++g) {
+                C8_CHUNK_SETUP(c)
+                if constexpr (PASSES == 3) {
+                    C8_STEP(0) C8_STEP(1) C8_STEP(2) C8_STEP(3) C8_STEP(4) C8_STEP(5) C8_STEP(6) C8_STEP(7) C8_STEP(8)
+                } else {
+                    C8_STEP2(0) C8_STEP2(1) C8_STEP2(2) C8_STEP2(3) C8_STEP2(4) C8_STEP2(5) C8_STEP2(6) C8_STEP2(7) C8_STEP2(8)
+                }
+            }
         }
         c8_wait_lgkm<0>();      // the prefetched fragments of the next tile have landed: their registers are stable
         epilogue();
@@ -584,19 +697,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         // The fragments the last step fetched for this tile's first step are fetched AGAIN here (their LDS images are
         // untouched: no DMA is issued during the epilogue): that makes the 16 + 8 NF fragment registers dead across the
         // epilogue, which needs them for its operand batches (see epilogue()).
-        {
-            const unsigned aw = lds_w_addr + sl * WSLOT, ab = lds_b_addr + (g & 1) * ACT_BYTES;
-            C8_RD(Alo[0], 2048, aw) C8_RD(Alo[1], 2048 + 512, aw)
-            C8_RD(Bhi[0], C8_ROW(0, 0, 0), ab)
-            if constexpr (NF > 1) C8_RD(Bhi[1], C8_ROW(1, 0, 0), ab)
-            if constexpr (NF > 2) C8_RD(Bhi[2], C8_ROW(2, 0, 0), ab)
-            if constexpr (NF > 3) C8_RD(Bhi[3], C8_ROW(3, 0, 0), ab)
-            C8_RDL(Blo[0], C8_ROW(0, 0, NPP * 16), ab)
-            if constexpr (NF > 1) C8_RDL(Blo[1], C8_ROW(1, 0, NPP * 16), ab)
-            if constexpr (NF > 2) C8_RDL(Blo[2], C8_ROW(2, 0, NPP * 16), ab)
-            if constexpr (NF > 3) C8_RDL(Blo[3], C8_ROW(3, 0, NPP * 16), ab)
-            c8_wait_lgkm<0>();
-        }
+        C8_PRIME(g)
     }
     c8_wait_vm<0>();        // no DMA may land in this block's LDS after it has been released
 }
@@ -747,7 +848,7 @@ extern "C" int dkt_conv_c8_pack_weights(const float *w, const int *src_channels,
 }
 
 // ---- launch
-template <int WM, int WN, int NF, int RING>
+template <int WM, int WN, int NF, int RING, int PASSES = 3>
 static int c8_launch(C8Args a, int B, hipStream_t st, const C8Args *second, int B2) {
     constexpr int NW = WM * WN, TR = WN * NF;
     constexpr int NU = (TR + 2) * C8_PC * 4;
@@ -758,7 +859,7 @@ static int c8_launch(C8Args a, int B, hipStream_t st, const C8Args *second, int 
         if (NW != 8 || NF > 2) return DKT_E_UNSUPPORTED;      // one block per CU: the extra LDS costs no residency
         lds += (size_t)NW * NF * 9 * 32 * 4;
     }
-    auto kern = conv_c8_kernel<WM, WN, NF, RING>;
+    auto kern = conv_c8_kernel<WM, WN, NF, RING, PASSES>;
     static int slots[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -863,20 +964,35 @@ static int c8_fill(C8Args &a, const dkt_conv_c8_desc *d) {
 
 // cfg: 0 = by shape; 1: 256 co x 8 rows (8 waves); 2: 128 co x 8 rows (8 waves); 3: 64 co x 8 rows (4 waves, two blocks per CU);
 //      4: 64 co x 4 rows (4 waves); 5: 256 co x 4 rows (4 waves, two blocks per CU); 6: 128 co x 8 rows (4 waves, two blocks per CU)
-static int c8_dispatch(const C8Args &a, int B, int cfg, hipStream_t st, const C8Args *second, int B2) {
+template <int PASSES>
+static int c8_dispatch_p(const C8Args &a, int B, int cfg, hipStream_t st, const C8Args *second, int B2) {
+    switch (cfg) {
+    case 1: return c8_launch<4, 2, 4, 4, PASSES>(a, B, st, second, B2);
+    case 2: return c8_launch<2, 4, 2, 4, PASSES>(a, B, st, second, B2);
+    case 3: return c8_launch<1, 4, 2, 6, PASSES>(a, B, st, second, B2);
+    case 4: return c8_launch<1, 4, 1, 8, PASSES>(a, B, st, second, B2);
+    default: break;
+    }
+    if constexpr (PASSES == 3) {          // (the 4-wave forms kept for the tests exist at full precision only)
+        if (cfg == 5) return c8_launch<4, 1, 4, 3>(a, B, st, second, B2);
+        if (cfg == 6) return c8_launch<2, 2, 4, 4>(a, B, st, second, B2);
+    }
+    return DKT_E_UNSUPPORTED;
+}
+
+static int c8_dispatch(const C8Args &a, int B, int cfg, int passes, hipStream_t st, const C8Args *second, int B2) {
     if (cfg == 0) {
         const long tiles8 = (long)((a.W + 31) / 32) * ((a.H + 7) / 8) * B;
         if (a.n_co64 >= 4 && tiles8 >= 128) cfg = 1;
         else if (a.n_co64 >= 2 && tiles8 * ((a.n_co64 + 1) / 2) >= 128) cfg = 2;
         else cfg = tiles8 * a.n_co64 >= 200 ? 3 : 4;
     }
-    switch (cfg) {
-    case 1: return c8_launch<4, 2, 4, 4>(a, B, st, second, B2);
-    case 2: return c8_launch<2, 4, 2, 4>(a, B, st, second, B2);
-    case 3: return c8_launch<1, 4, 2, 6>(a, B, st, second, B2);
-    case 4: return c8_launch<1, 4, 1, 8>(a, B, st, second, B2);
-    case 5: return c8_launch<4, 1, 4, 3>(a, B, st, second, B2);
-    case 6: return c8_launch<2, 2, 4, 4>(a, B, st, second, B2);
+    // (one pass: the chunk loop runs two chunks per trip -- odd chunk counts take two passes or more)
+    if (passes == 1 && ((a.nchunks & 1) || (second && (second->nchunks & 1)))) return DKT_E_UNSUPPORTED;
+    switch (passes) {
+    case 0: case 3: return c8_dispatch_p<3>(a, B, cfg, st, second, B2);
+    case 2: return c8_dispatch_p<2>(a, B, cfg, st, second, B2);
+    case 1: return c8_dispatch_p<1>(a, B, cfg, st, second, B2);
     default: return DKT_E_UNSUPPORTED;
     }
 }
@@ -886,7 +1002,7 @@ extern "C" int dkt_conv2d_c8(const dkt_conv_c8_desc *d, int cfg, int device, voi
     const int rc = c8_fill(a, d);
     if (rc != DKT_OK) return rc;
     DKT_ENTER(device);
-    return c8_dispatch(a, d->B, cfg, (hipStream_t)stream, nullptr, 0);
+    return c8_dispatch(a, d->B, cfg, d->passes, (hipStream_t)stream, nullptr, 0);
 }
 
 extern "C" int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_desc *d1, int cfg, int device, void *stream) {
@@ -896,8 +1012,9 @@ extern "C" int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_
     rc = c8_fill(b, d1);
     if (rc != DKT_OK) return rc;
     if (cfg == 0) return DKT_E_UNSUPPORTED;          // both problems run one instantiation: the caller names it
+    if ((d0->passes ? d0->passes : 3) != (d1->passes ? d1->passes : 3)) return DKT_E_UNSUPPORTED;
     DKT_ENTER(device);
-    return c8_dispatch(a, d0->B, cfg, (hipStream_t)stream, &b, d1->B);
+    return c8_dispatch(a, d0->B, cfg, d0->passes, (hipStream_t)stream, &b, d1->B);
 }
 
 // ---- second layer of the flow / disparity head from the planes of epilogue 3 (core/update.py:10-13, 3x3, padding 1):

@@ -83,7 +83,11 @@ __device__ __forceinline__ void g8_wait_lgkm() {
 
 typedef __attribute__((address_space(1))) unsigned g8_gu32;
 
+// PASSES (round 5): fp16 MFMA products per weight x activation block, as conv_c8.hip's: 3 = fp32-class (w_hi x_hi + w_lo x_hi +
+// w_hi x_lo), 2 = without w_hi x_lo, 1 = w_hi x_hi only.  Gates, state update and every stored tensor are the same in all three.
+template <int PASSES>
 __global__ __launch_bounds__(512, 1) void gru_c8_kernel(G8ArgsPair ap, int nb0) {
+    static_assert(PASSES >= 1 && PASSES <= 3, "passes");
     constexpr int NW = 8, WM = 4, NF = 4, TR = 8, PR = TR + 2;
     constexpr int NPP = PR * G8_PC;                  // 340 patch pixels
     constexpr int NU = NPP * 4;                      // 16-byte units per chunk
@@ -298,18 +302,118 @@ __global__ __launch_bounds__(512, 1) void gru_c8_kernel(G8ArgsPair ap, int nb0) 
         if constexpr (MFP == 2) G8_MM(Ahi, 1, Blo, 3 + DY, 3)                                                          \
         sl = sl1;                                                                                                      \
     }
-    // the fragments a phase's first step does not fetch itself (after the DMA of its first patch and image has landed)
+    // the fragments a phase's first step does not fetch itself (after the DMA of its first patch and image has landed).
+    // PASSES == 1 keeps the A fragments double-buffered in Ahi / Alo: a chunk has nine steps, so even chunks of a phase compute
+    // their first step from Ahi and odd ones from Alo -- the chunk loops run two chunks per trip (the host refuses odd chunk
+    // counts at one pass), because a run-time choice between the two step sequences sent the accumulators to scratch.
 #define G8_FIRST_FRAGS(MFP)                                                                              \
     {                                                                                                    \
         const unsigned aw = (MFP == 2 ? lds_wA : lds_wB) + sl * WSLOT, ab = lds_b_addr + (g & 1) * ACT_BYTES; \
-        G8_RD(Alo[0], 2048, aw)                                                                          \
-        if constexpr (MFP == 2) G8_RD(Alo[1], 2048 + 512, aw)                                            \
+        if constexpr (PASSES == 1) {                                                                     \
+            G8_RD(Ahi[0], 0, aw) if constexpr (MFP == 2) G8_RD(Ahi[1], 512, aw)                          \
+        } else {                                                                                         \
+            G8_RD(Alo[0], 2048, aw)                                                                      \
+            if constexpr (MFP == 2) G8_RD(Alo[1], 2048 + 512, aw)                                        \
+        }                                                                                                \
         G8_RD(Bhi[0], G8_ROW(0, 0, 0), ab) G8_RD(Bhi[1], G8_ROW(1, 0, 0), ab)                            \
         G8_RD(Bhi[2], G8_ROW(2, 0, 0), ab) G8_RD(Bhi[3], G8_ROW(3, 0, 0), ab)                            \
-        G8_RD(Blo[0], G8_ROW(0, 0, NPP * 16), ab) G8_RD(Blo[1], G8_ROW(1, 0, NPP * 16), ab)              \
-        G8_RD(Blo[2], G8_ROW(2, 0, NPP * 16), ab) G8_RD(Blo[3], G8_ROW(3, 0, NPP * 16), ab)              \
+        if constexpr (PASSES == 3) {                                                                     \
+            G8_RD(Blo[0], G8_ROW(0, 0, NPP * 16), ab) G8_RD(Blo[1], G8_ROW(1, 0, NPP * 16), ab)          \
+            G8_RD(Blo[2], G8_ROW(2, 0, NPP * 16), ab) G8_RD(Blo[3], G8_ROW(3, 0, NPP * 16), ab)          \
+        }                                                                                                \
         g8_wait_lgkm<0>();                                                                               \
     }
+    // ---- reduced-pass steps (conv_c8.hip's C8_STEP2 / C8_STEP1 at NF = 4): same DMA stream and vmcnt waits as G8_STEP
+#define G8_STEP_HEAD(T, MFP)                                                                                           \
+        constexpr int DX = (T) / 3, DY = (T) % 3, NDX = (DX + 1) % 3;                                                  \
+        constexpr int WPI = (MFP), MFPV = (MFP);                                                                       \
+        const int sl1 = sl + 1 == RING ? 0 : sl + 1, sl2 = sl == 0 ? RING - 1 : sl - 1;                                \
+        const unsigned adw_s = (MFP == 2 ? lds_wA : lds_wB) + sl * WSLOT;                                              \
+        const unsigned adw_n = (MFP == 2 ? lds_wA : lds_wB) + sl1 * WSLOT;                                             \
+        const unsigned adb_c = lds_b_addr + cur * ACT_BYTES;                                                           \
+        const unsigned adb_n = lds_b_addr + (DX < 2 ? cur : nxt) * ACT_BYTES;                                          \
+        (void)adw_s; (void)adw_n; (void)adb_c; (void)adb_n;                                                            \
+        if ((T) == 1) g8_wait_vm<WPI + NIA>();                                                                         \
+        else if ((T) >= 7 && MFP == 2) { if (last) g8_wait_vm<1>(); else g8_wait_vm<2>(); }                            \
+        else g8_wait_vm<WPI>();                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        if constexpr (DY == 0) g8_wait_lgkm<0>(); else g8_wait_lgkm<1>();                                              \
+        __builtin_amdgcn_sched_barrier(0);
+#define G8_STEP_DMA(T, MFP)                                                                                            \
+        if ((T) == 6 && last) wptr = w_next;                                                                           \
+        if ((T) == 0) { if (use_nxt_off) issue_act(act_f, aoff_nxt, nxt); else issue_act(act_f, aoff_cur, nxt); }      \
+        if ((T) >= 6 && last) {                                                                                        \
+            if constexpr (MFP == 2) { issue_wB(wptr, sl2); wptr += WSTEP_B; }                                          \
+            else { issue_wA(wptr, sl2); wptr += WSTEP_A; }                                                             \
+        } else {                                                                                                       \
+            if constexpr (MFP == 2) { issue_wA(wptr, sl2); wptr += WSTEP_A; }                                          \
+            else { issue_wB(wptr, sl2); wptr += WSTEP_B; }                                                             \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);
+    // two passes.  LDS reads in issue order: X: Ahi[0] (, Ahi[1]); dy < 2: row NF + dy.  Y: Alo'[0] (, Alo'[1]), the dying rows
+#define G8_STEP2(T, MFP)                                                                                               \
+    {                                                                                                                  \
+        G8_STEP_HEAD(T, MFP)                                                                                           \
+        G8_MM(Alo, 0, Bhi, DY, 0) G8_RD(Ahi[0], 0, adw_s)                                                              \
+        if constexpr (MFP == 2) { G8_MM(Alo, 1, Bhi, DY, 0) G8_RD(Ahi[1], 512, adw_s) }                                \
+        G8_MM(Alo, 0, Bhi, 1 + DY, 1)                                                                                  \
+        if constexpr (DY < 2) G8_RD(Bhi[NF + DY], G8_ROW(NF + DY, DX, 0), adb_c)                                       \
+        if constexpr (MFP == 2) G8_MM(Alo, 1, Bhi, 1 + DY, 1)                                                          \
+        G8_MM(Alo, 0, Bhi, 2 + DY, 2)                                                                                  \
+        if constexpr (MFP == 2) G8_MM(Alo, 1, Bhi, 2 + DY, 2)                                                          \
+        G8_MM(Alo, 0, Bhi, 3 + DY, 3)                                                                                  \
+        if constexpr (MFP == 2) G8_MM(Alo, 1, Bhi, 3 + DY, 3)                                                          \
+        G8_STEP_DMA(T, MFP)                                                                                            \
+        g8_wait_lgkm<(DY < 2 ? 1 : 0)>();                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        G8_MM(Ahi, 0, Bhi, DY, 0) G8_RD(Alo[0], 2048, adw_n)                                                           \
+        if constexpr (MFP == 2) { G8_MM(Ahi, 1, Bhi, DY, 0) G8_RD(Alo[1], 2048 + 512, adw_n) }                         \
+        if constexpr (DY == 0) G8_RD(Bhi[0], G8_ROW(0, NDX, 0), adb_n)                                                 \
+        if constexpr (DY == 1) G8_RD(Bhi[1], G8_ROW(1, NDX, 0), adb_n)                                                 \
+        if constexpr (DY == 2) G8_RD(Bhi[2], G8_ROW(2, NDX, 0), adb_n)                                                 \
+        G8_MM(Ahi, 0, Bhi, 1 + DY, 1)                                                                                  \
+        if constexpr (MFP == 2) G8_MM(Ahi, 1, Bhi, 1 + DY, 1)                                                          \
+        if constexpr (DY == 2) G8_RD(Bhi[3], G8_ROW(3, NDX, 0), adb_n)                                                 \
+        G8_MM(Ahi, 0, Bhi, 2 + DY, 2)                                                                                  \
+        if constexpr (MFP == 2) G8_MM(Ahi, 1, Bhi, 2 + DY, 2)                                                          \
+        G8_MM(Ahi, 0, Bhi, 3 + DY, 3)                                                                                  \
+        if constexpr (MFP == 2) G8_MM(Ahi, 1, Bhi, 3 + DY, 3)                                                          \
+        sl = sl1;                                                                                                      \
+    }
+    // one pass: A fragments double-buffered (PA: this step's, PB: the next step's, fetched behind the barrier), row by row
+#define G8_STEP1(T, MFP, PA, PB)                                                                                       \
+    {                                                                                                                  \
+        G8_STEP_HEAD(T, MFP)                                                                                           \
+        G8_RD(PB[0], 0, adw_n)                                                                                         \
+        if constexpr (MFP == 2) G8_RD(PB[1], 512, adw_n)                                                               \
+        if constexpr (DY < 2) G8_RD(Bhi[NF + DY], G8_ROW(NF + DY, DX, 0), adb_c)                                       \
+        G8_MM(PA, 0, Bhi, DY, 0)                                                                                       \
+        if constexpr (MFP == 2) G8_MM(PA, 1, Bhi, DY, 0)                                                               \
+        if constexpr (DY == 0) G8_RD(Bhi[0], G8_ROW(0, NDX, 0), adb_n)                                                 \
+        if constexpr (DY == 1) G8_RD(Bhi[1], G8_ROW(1, NDX, 0), adb_n)                                                 \
+        if constexpr (DY == 2) G8_RD(Bhi[2], G8_ROW(2, NDX, 0), adb_n)                                                 \
+        G8_STEP_DMA(T, MFP)                                                                                            \
+        G8_MM(PA, 0, Bhi, 1 + DY, 1)                                                                                   \
+        if constexpr (MFP == 2) G8_MM(PA, 1, Bhi, 1 + DY, 1)                                                           \
+        if constexpr (DY == 2) G8_RD(Bhi[3], G8_ROW(3, NDX, 0), adb_n)                                                 \
+        G8_MM(PA, 0, Bhi, 2 + DY, 2)                                                                                   \
+        if constexpr (MFP == 2) G8_MM(PA, 1, Bhi, 2 + DY, 2)                                                           \
+        G8_MM(PA, 0, Bhi, 3 + DY, 3)                                                                                   \
+        if constexpr (MFP == 2) G8_MM(PA, 1, Bhi, 3 + DY, 3)                                                           \
+        sl = sl1;                                                                                                      \
+    }
+#define G8_CHUNK(MFP)                                                                                                  \
+    if constexpr (PASSES == 3) {                                                                                       \
+        G8_STEP(0, MFP) G8_STEP(1, MFP) G8_STEP(2, MFP) G8_STEP(3, MFP) G8_STEP(4, MFP) G8_STEP(5, MFP) G8_STEP(6, MFP) \
+        G8_STEP(7, MFP) G8_STEP(8, MFP)                                                                                \
+    } else {                                                                                                           \
+        G8_STEP2(0, MFP) G8_STEP2(1, MFP) G8_STEP2(2, MFP) G8_STEP2(3, MFP) G8_STEP2(4, MFP) G8_STEP2(5, MFP)          \
+        G8_STEP2(6, MFP) G8_STEP2(7, MFP) G8_STEP2(8, MFP)                                                             \
+    }
+#define G8_CHUNK1(MFP, PA, PB)                                                                                         \
+    G8_STEP1(0, MFP, PA, PB) G8_STEP1(1, MFP, PB, PA) G8_STEP1(2, MFP, PA, PB) G8_STEP1(3, MFP, PB, PA)                \
+    G8_STEP1(4, MFP, PA, PB) G8_STEP1(5, MFP, PB, PA) G8_STEP1(6, MFP, PA, PB) G8_STEP1(7, MFP, PB, PA)                \
+    G8_STEP1(8, MFP, PA, PB)
 
     // ---- C8S stores: the lane's channel quads (r >> 2 = j) of a pair (2 jp, 2 jp + 1) are completed to 8-channel groups with
     // lane ^ 32 (v_permlane32_swap), after which the lane holds group 2 jp + kg of the wave's 32-channel block
@@ -500,13 +604,24 @@ __global__ __launch_bounds__(512, 1) void gru_c8_kernel(G8ArgsPair ap, int nb0) 
         const int ntxy = have_next ? tn - nb * a.tiles_xy : txy;
         const int nw0 = (ntxy % a.tiles_w) * 32, nh0 = (ntxy / a.tiles_w) * TR;
         // ---------------- phase A: z | r
-        for (int c = 0; c < nA; ++c, ++g) {
-            const bool last = c + 1 == nA;
-            const char *act_f = last ? chunk_B(b, 0) : chunk_A(b, c + 1);
-            const char *w_next = a.wq;
-            constexpr bool use_nxt_off = false;
+#define G8_A_SETUP(c)                                                              \
+            const bool last = (c) + 1 == nA;                                           \
+            const char *act_f = last ? chunk_B(b, 0) : chunk_A(b, (c) + 1);            \
+            const char *w_next = a.wq;                                                 \
+            constexpr bool use_nxt_off = false;                                        \
             const int cur = g & 1, nxt = cur ^ 1;
-            G8_STEP(0, 2) G8_STEP(1, 2) G8_STEP(2, 2) G8_STEP(3, 2) G8_STEP(4, 2) G8_STEP(5, 2) G8_STEP(6, 2) G8_STEP(7, 2) G8_STEP(8, 2)
+        if constexpr (PASSES == 1) {
+            for (int c = 0; c < nA; c += 2) {
+                { G8_A_SETUP(c) G8_CHUNK1(2, Ahi, Alo) }
+                ++g;
+                { G8_A_SETUP(c + 1) G8_CHUNK1(2, Alo, Ahi) }
+                ++g;
+            }
+        } else {
+            for (int c = 0; c < nA; ++c, ++g) {
+                G8_A_SETUP(c)
+                G8_CHUNK(2)
+            }
         }
         g8_wait_lgkm<0>();
         // @trace(2)
@@ -519,15 +634,26 @@ __global__ __launch_bounds__(512, 1) void gru_c8_kernel(G8ArgsPair ap, int nb0) 
         G8_FIRST_FRAGS(1)
         // @trace(3)
         // ---------------- phase B: q
-        for (int c = 0; c < nB; ++c, ++g) {
-            const bool last = c + 1 == nB;
-            if (c == a.nxc - 1) wait_neighbours();       // before the barrier that precedes the first r*h patch's DMA
-            const char *act_f = last ? (have_next ? chunk_A(nb, 0) : chunk_B(b, c)) : chunk_B(b, c + 1);
-            const char *w_next = a.wzr;
-            const bool use_nxt_off = last && have_next;
-            if (use_nxt_off) tile_offsets(nh0, nw0, aoff_nxt);
+#define G8_B_SETUP(c)                                                                                                  \
+            const bool last = (c) + 1 == nB;                                                                           \
+            if ((c) == a.nxc - 1) wait_neighbours();       /* before the barrier that precedes the first r*h patch's DMA */ \
+            const char *act_f = last ? (have_next ? chunk_A(nb, 0) : chunk_B(b, (c))) : chunk_B(b, (c) + 1);           \
+            const char *w_next = a.wzr;                                                                                \
+            const bool use_nxt_off = last && have_next;                                                                \
+            if (use_nxt_off) tile_offsets(nh0, nw0, aoff_nxt);                                                         \
             const int cur = g & 1, nxt = cur ^ 1;
-            G8_STEP(0, 1) G8_STEP(1, 1) G8_STEP(2, 1) G8_STEP(3, 1) G8_STEP(4, 1) G8_STEP(5, 1) G8_STEP(6, 1) G8_STEP(7, 1) G8_STEP(8, 1)
+        if constexpr (PASSES == 1) {
+            for (int c = 0; c < nB; c += 2) {
+                { G8_B_SETUP(c) G8_CHUNK1(1, Ahi, Alo) }
+                ++g;
+                { G8_B_SETUP(c + 1) G8_CHUNK1(1, Alo, Ahi) }
+                ++g;
+            }
+        } else {
+            for (int c = 0; c < nB; ++c, ++g) {
+                G8_B_SETUP(c)
+                G8_CHUNK(1)
+            }
         }
         g8_wait_lgkm<0>();
         // @trace(4)
@@ -592,6 +718,9 @@ extern "C" long dkt_gru_c8_flag_words(int B, int H, int W) {
     return (long)((W + 31) / 32) * ((H + 7) / 8) * B;
 }
 
+template <int PASSES>
+static int g8_launch_p(const G8ArgsPair &ap, bool pair, hipStream_t st);
+
 static int g8_launch(const dkt_gru_c8_desc *d0, const dkt_gru_c8_desc *d1, unsigned *err, hipStream_t st) {
     G8ArgsPair ap;
     int rc = g8_fill(ap.p[0], d0);
@@ -602,8 +731,51 @@ static int g8_launch(const dkt_gru_c8_desc *d0, const dkt_gru_c8_desc *d1, unsig
         if (rc != DKT_OK) return rc;
     }
     ap.err = err;
+    const int p0 = d0->passes ? d0->passes : 3, p1 = d1 ? (d1->passes ? d1->passes : 3) : p0;
+    if (p0 != p1) return DKT_E_UNSUPPORTED;
+    if (p0 == 1 && ((ap.p[0].nxc & 1) || (d1 && (ap.p[1].nxc & 1)))) return DKT_E_UNSUPPORTED;     // (two chunks per loop trip)
+    switch (p0) {
+    case 3: return g8_launch_p<3>(ap, d1 != nullptr, st);
+    case 2: return g8_launch_p<2>(ap, d1 != nullptr, st);
+    case 1: return g8_launch_p<1>(ap, d1 != nullptr, st);
+    default: return DKT_E_UNSUPPORTED;
+    }
+}
+
+// How the launch's blocks are split between its two problems when the device cannot hold one block per tile (round 5).  A
+// block walks its problem's tiles with a fixed stride, and a tile waits for its 3x3 neighbours: when the stride is a multiple
+// of the tiles of ONE image, every round of the launch is closed under the neighbour relation (no tile waits for a tile of the
+// next round) -- round 4 split the blocks by work alone (243 + 13 at cfg4's 8 pairs per GPU: the rider's 13 blocks took 12
+// rounds while the others took 8, and the last tiles of every round waited for the first of the next: 3731 us per launch
+// against 8 x 395).  Cost model: rounds x (chunks + a fixed part) per problem; ties go to image-aligned strides.
+static void g8_split(const G8ArgsPair &ap, long cap, long &nb0, long &nb1) {
+    const long total0 = ap.p[0].total_tiles, total1 = ap.p[1].total_tiles;
+    const double c0 = 16 + 2 * ap.p[0].nxc + 10, c1 = 16 + 2 * ap.p[1].nxc + 10;
+    double best = 1e300;
+    nb0 = 1; nb1 = 1;
+    for (long n1 = 1; n1 <= total1 && n1 < cap; ++n1) {
+        const long room = cap - n1;
+        long cand[2] = {room < total0 ? room : total0, 0};
+        const long txy = ap.p[0].tiles_xy;
+        cand[1] = (cand[0] >= txy && cand[0] < total0) ? cand[0] / txy * txy : cand[0];
+        for (int k = 0; k < 2; ++k) {
+            const long n0 = cand[k];
+            if (n0 < 1) continue;
+            const double r0 = (double)((total0 + n0 - 1) / n0) * c0, r1 = (double)((total1 + n1 - 1) / n1) * c1;
+            double cost = r0 > r1 ? r0 : r1;
+            const bool aligned0 = n0 >= total0 || n0 % txy == 0;
+            const bool aligned1 = n1 >= total1 || n1 % ap.p[1].tiles_xy == 0;
+            cost *= 1.0 + (aligned0 ? 0.0 : 0.06) + (aligned1 ? 0.0 : 0.02);        // what the cross-round waits cost, measured
+            cost += 1e-6 * (n0 + n1);                                               // (fewer blocks when nothing else decides)
+            if (cost < best) { best = cost; nb0 = n0; nb1 = n1; }
+        }
+    }
+}
+
+template <int PASSES>
+static int g8_launch_p(const G8ArgsPair &ap, bool pair, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 23 * 1024 + (size_t)4 * 16384;
-    auto kern = gru_c8_kernel;
+    auto kern = gru_c8_kernel<PASSES>;
     static int slots[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -616,22 +788,16 @@ static int g8_launch(const dkt_gru_c8_desc *d0, const dkt_gru_c8_desc *d1, unsig
         slots[dev & 63] = cus;             // one 110 KB block per CU
     }
     const long cap = slots[dev & 63];
-    const long total0 = ap.p[0].total_tiles, total1 = d1 ? ap.p[1].total_tiles : 0;
+    const long total0 = ap.p[0].total_tiles, total1 = pair ? ap.p[1].total_tiles : 0;
     long nb0 = total0 > cap ? cap : total0, nb1 = 0;
-    if (d1) {
+    if (nb0 < total0 && nb0 >= ap.p[0].tiles_xy) nb0 = nb0 / ap.p[0].tiles_xy * ap.p[0].tiles_xy;      // whole images per round
+    if (pair) {
         nb0 = total0; nb1 = total1;
-        if (total0 + total1 > cap) {
-            const double w0 = (double)total0 * (16 + 2 * ap.p[0].nxc), w1 = (double)total1 * (16 + 2 * ap.p[1].nxc);
-            nb1 = (long)(cap * w1 / (w0 + w1) + 0.5);
-            nb1 = nb1 < 1 ? 1 : (nb1 > total1 ? total1 : nb1);
-            nb0 = cap - nb1;
-            if (nb0 > total0) nb0 = total0;
-            if (nb0 < 1) return DKT_E_UNSUPPORTED;
-        }
+        if (total0 + total1 > cap) g8_split(ap, cap, nb0, nb1);
     }
     // a block's next tile must not be a neighbour of (or precede a neighbour of) its current one: stride >= tiles_w + 2
     if (nb0 < total0 && nb0 < ap.p[0].tiles_w + 2) return DKT_E_UNSUPPORTED;
-    if (d1 && nb1 < total1 && nb1 < ap.p[1].tiles_w + 2) return DKT_E_UNSUPPORTED;
+    if (pair && nb1 < total1 && nb1 < ap.p[1].tiles_w + 2) return DKT_E_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb0 + nb1)), dim3(512), lds, st, ap, (int)nb0);
     return dkt_launch_status();
 }

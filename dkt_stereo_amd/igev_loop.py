@@ -20,6 +20,7 @@ import weakref
 import torch
 
 from . import conv as _conv
+from . import conv_c8 as c8
 from . import loop_c8
 from .conv import conv2d
 from .update import FUSE_GATES, GPU_GUARD, _side_stream, capture_graph, gru_pair, harness, interp, pool2x, replay_graph
@@ -65,20 +66,22 @@ def _iterate_c8(ub, st, iters):
     with harness(inplace_state=True, side_stream=False):
         if not lp.calibrated:
             lp.calibrate(d, iters)               # activation scales from a trial run on this pair (state restored)
-        lp.prologue(d)
+        with c8.passes(lp.plan(iters)[0]):
+            lp.prologue(d)
         # every unit also advances the coarsest GRU for the NEXT iteration (it rides in the finest GRU's launches); the caller
         # gets the state the reference's loop ends with: the coarsest state is saved in front of the last unit
         done = 0
+        plan = lp.plan(iters)
         if lp.graph is None:
             if iters == 1:
                 keep = st.net[2].clone()
-            lp.unit(d, last=(iters == 1))        # eager once: packs weights, sizes the allocator
-            lp.capture(d, capture_graph)         # (capturing records, it does not execute)
+            with c8.passes(plan[0]):
+                lp.unit(d, last=(iters == 1))    # eager once: packs weights, sizes the allocator
             done = 1
         if iters > done:
-            lp.replay(iters - 1 - done)
+            lp.replay(plan[done:-1], d, capture_graph)
             keep = st.net[2].clone()
-            lp.replay(1, last=True)
+            lp.replay(plan[-1:], d, capture_graph, last=True)
         st.net[2].copy_(keep)
         mask = conv2d(st.net[0], ub.mask_feat_4[0], relu=True)
     return st.disp.clone(), mask, [t.clone() for t in st.net]

@@ -55,6 +55,23 @@ HEAD_FIRST = True
 #: the bulk of the iterations is replayed GRAPH_UNITS units at a time (a one-unit graph serves the remainder)
 GRAPH_UNITS = max(1, int(os.environ.get("DKT_C8_GRAPH_UNITS", "8")))
 
+#: round 5 -- precision schedule of the loop's convolutions (csrc/conv_c8.hip, gru_c8.hip `passes`): (k1, k2) = the first k1 units at
+#: ONE fp16 MFMA product per block (weights and activations rounded to fp16), the next k2 at TWO (activations rounded), the rest at
+#: the fp32-class three.  None = three throughout: the parity path and the default.  The refinement is contractive (SURVEY 7:
+#: noise of 1e-4 on every lookup moves the result by 3.8e-5), so the arithmetic of the early iterations -- which only have to
+#: bring the disparity close -- is largely forgotten by the final fp32-class ones; what a schedule costs against the reference
+#: fixtures is measured in profiles/r05_precision_schedule.txt (tools/precision_schedule.py).  The reference's own switch of this
+#: kind is `mixed_precision` (raft_stereo.py:95,156).  DKT_C8_SCHEDULE="k1,k2" sets the default.
+def _env_schedule():
+    v = os.environ.get("DKT_C8_SCHEDULE", "")
+    if not v:
+        return None
+    k = [int(x) for x in v.split(",")]
+    return (k[0], k[1] if len(k) > 1 else 0)
+
+
+SCHEDULE = _env_schedule()
+
 #: quarter-resolution pixels (per pair) from which the loop takes this path.  Round 4: every size does (small images on the
 #: two-launch form of the finest GRU with 4-row tiles, see C8Loop.__init__): 256 x 512 / 32 iterations 9.5 ms against 12.1 on
 #: the round-2 kernels; the variable remains as the A/B handle
@@ -141,49 +158,71 @@ class C8Loop:
         self.par = 0                     # which of self.cx holds the current x coordinate
         self.cx = None
         self.calibrated = not AUTOSCALE
+        self.schedule = SCHEDULE         # (k1, k2) or None, see SCHEDULE
+
+    def plan(self, iters):
+        """MFMA passes of each of the `iters` units."""
+        if not self.schedule:
+            return [3] * iters
+        k1, k2 = self.schedule
+        return [1 if i < k1 else 2 if i < k1 + k2 else 3 for i in range(iters)]
 
     # ---- captured units -------------------------------------------------------------------------------------------
     def _front_supported(self, st):
         from . import conv_c8
         return "corr" in st and conv_c8.motion_front_supported(st["corr"], self.ub.encoder)
 
-    def capture(self, st, capture_graph):
+    def capture(self, st, capture_graph, passes=3):
         """Captures one unit, the final unit, and GRAPH_UNITS units back to back (capturing records, it does not execute) --
-        with the fused front once per parity of the coordinate buffer the sequence starts from."""
-        self._mask(st)          # eager once: the final unit's own layers are packed (with the calibrated scales) outside the capture
+        with the fused front once per parity of the coordinate buffer the sequence starts from -- at `passes` MFMA products per
+        block (graphs are kept per (passes, parity): a precision schedule replays units of several kinds)."""
+        with c8.passes(passes):
+            self._mask(st)      # eager once: the final unit's own layers are packed (with the calibrated scales) outside the capture
         torch.cuda.synchronize()
         keep = self.par
-        self.graph, self.graph_last, self.graph_n = {}, {}, {}
-        self.pinned = []                 # the packed weight images the captured launches point to (conv_c8.pin_packs)
+        if self.graph is None:
+            self.graph, self.graph_last, self.graph_n = {}, {}, {}
+            self.pinned = []             # the packed weight images the captured launches point to (conv_c8.pin_packs)
         for p in ((0, 1) if self.front else (0,)):
             def cap(fn):
                 self.par = p
                 g = torch.cuda.CUDAGraph()
-                with capture_graph(g), c8.pin_packs(self.pinned):
+                with capture_graph(g), c8.pin_packs(self.pinned), c8.passes(passes):
                     fn()
                 return g
             with _ffi.launch_log() as names:
-                self.graph[p] = cap(lambda: self.unit(st))
+                self.graph[passes, p] = cap(lambda: self.unit(st))
             self.unit_launches = list(names)          # the dispatches of one captured unit (tests pin their number)
-            self.graph_last[p] = cap(lambda: self.unit(st, last=True))
+            self.graph_last[passes, p] = cap(lambda: self.unit(st, last=True))
             if GRAPH_UNITS > 1:
-                self.graph_n[p] = cap(lambda: [self.unit(st) for _ in range(GRAPH_UNITS)])
+                self.graph_n[passes, p] = cap(lambda: [self.unit(st) for _ in range(GRAPH_UNITS)])
         self.par = keep
 
-    def replay(self, n, last=False):
-        """n units from the captured graphs (`last`: the n-th is the pair's final one)."""
-        if last:
-            n -= 1
+    def replay(self, plan, st, capture_graph, last=False):
+        """One captured unit per entry of `plan` (its MFMA passes); `last`: the final entry is the pair's final unit."""
+        plan = list(plan)
+        for p in sorted(set(plan)):
+            if (p, 0) not in self.graph:
+                self.capture(st, capture_graph, p)          # (first use of this kind of unit: once per state)
+        tail = plan.pop() if last else None
         step = GRAPH_UNITS if GRAPH_UNITS % 2 == 0 or not self.front else 0      # (an odd run of units would end on the other parity)
-        while self.graph_n and step and n >= step:
-            self.graph_n[self.par].replay()
-            n -= step
-        for _ in range(n):
-            self.graph[self.par].replay()
-            if self.front:
-                self.par ^= 1
+        i = 0
+        while i < len(plan):
+            p = plan[i]
+            run = 1
+            while i + run < len(plan) and plan[i + run] == p:
+                run += 1
+            n = run
+            while self.graph_n and step and n >= step:
+                self.graph_n[p, self.par].replay()
+                n -= step
+            for _ in range(n):
+                self.graph[p, self.par].replay()
+                if self.front:
+                    self.par ^= 1
+            i += run
         if last:
-            self.graph_last[self.par].replay()
+            self.graph_last[tail, self.par].replay()
             self.par = 0                 # (the final unit leaves the coordinate in st["coords1"])
 
     _tail_channels = 2                   # flow (x, y) behind the 126 motion features (core/update.py:85)

@@ -636,6 +636,10 @@ class RAFTStereo(nn.Module):
 
     #: round 3: the loop on the C8S convolution (loop_c8.py); DKT_C8=0 keeps the round-2 kernels and schedule
     use_c8 = os.environ.get("DKT_C8", "1") != "0"
+    #: round 5: (k1, k2) = the first k1 refinement iterations at one fp16 MFMA product per block, the next k2 at two, the rest at
+    #: the fp32-class three (loop_c8.SCHEDULE); None = fp32-class throughout (the default and the parity path); False = whatever
+    #: DKT_C8_SCHEDULE says.  The reference's switch of this kind: `mixed_precision`, raft_stereo.py:95,156
+    precision_schedule = False
     c8_eager = False
 
     def _iterate_c8(self, st, iters):
@@ -649,21 +653,27 @@ class RAFTStereo(nn.Module):
             st["feat"], st["flow"] = self.update_block.encoder.new_feature_buffer(b, h, w, st["coords1"].device)
         torch.sub(st["coords1"], st["coords0"], out=st["flow"])
         ub = self.update_block
+        from . import conv_c8
+        if self.precision_schedule is not False:          # (False: leave the loop's own setting alone)
+            lp.schedule = self.precision_schedule
+        plan = lp.plan(iters)                # MFMA passes per unit: 3 throughout unless a precision schedule is set
         with harness(inplace_state=True, side_stream=False):
             if not lp.calibrated:
                 lp.calibrate(st, iters)      # activation scales from a trial run on this pair (state restored)
-            lp.prologue(st)
+            with conv_c8.passes(plan[0]):
+                lp.prologue(st)
             done = 0
             if self.c8_eager:                # (bench.py's instrumented pass: every unit as plain launches)
                 for k in range(iters):
-                    lp.unit(st, last=(k + 1 == iters))
+                    with conv_c8.passes(plan[k]):
+                        lp.unit(st, last=(k + 1 == iters))
                 done = iters
             elif lp.graph is None:
-                lp.unit(st, last=(iters == 1))       # eager once: packs weights, sizes the allocator
+                with conv_c8.passes(plan[0]):
+                    lp.unit(st, last=(iters == 1))   # eager once: packs weights, sizes the allocator
                 done = 1
-                lp.capture(st, capture_graph)        # (capturing does not execute: still one unit done)
             if iters > done:
-                lp.replay(iters - done, last=True)
+                lp.replay(plan[done:], st, capture_graph, last=True)     # (captures the kinds of unit it has not yet)
             # up-sampling mask head (core/update.py:107-110, :136) from the final hidden state: the final unit computes it
             # beside the flow head (loop_c8.C8Loop._mask)
             if lp.mask_out is not None:

@@ -466,6 +466,11 @@ typedef struct dkt_conv_c8_desc {
                                              * lane and channel quad in the epilogue) instead of NCHW; bstrides stay in floats */
     float tail_scale;                       /* power of two applied to the `tail` channels of the C8S output instead of act_scale
                                              * (0 = act_scale): flow / disparity values next to features of another magnitude */
+    int passes;                             /* round 5: fp16 MFMA products per weight x activation block. 0 / 3 = w_hi x_hi + w_lo x_hi +
+                                             * w_hi x_lo (fp32-class, the parity path); 2 = without w_hi x_lo (activations rounded to
+                                             * fp16); 1 = w_hi x_hi only.  Reduced passes serve the precision schedules of the
+                                             * refinement loop (the reference's own switch: raft_stereo.py:95,156 `mixed_precision`);
+                                             * tile shapes 1..4 */
 } dkt_conv_c8_desc;
 /* cfg: 0 = tile shape by layer / image size, 1..5 force one (conv_c8.hip c8_dispatch). */
 int dkt_conv2d_c8(const dkt_conv_c8_desc *d, int cfg, int device, void *stream);
@@ -503,6 +508,7 @@ typedef struct dkt_gru_c8_desc {
     float scale_zr, scale_q, act_scale;
     int B, H, W, hidden;
     unsigned *flags;
+    int passes;                                 /* as dkt_conv_c8_desc.passes (0 / 3, 2, 1); both steps of a pair launch alike */
 } dkt_gru_c8_desc;
 long dkt_gru_c8_flag_words(int B, int H, int W);
 int dkt_gru_c8(const dkt_gru_c8_desc *d, unsigned *err_word, int device, void *stream);

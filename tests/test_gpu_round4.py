@@ -353,7 +353,7 @@ def test_encoder_outputs_in_place_and_prebuilt_volume_change_nothing():
     f1, f2, net, inp = a.encode(*pairs[1])
     assert [t.data_ptr() for t in net] == [t.data_ptr() for t in st["net"]]
     assert [t.data_ptr() for sc in inp for t in sc] == [t.data_ptr() for sc in st["inp"] for t in sc]
-    assert a._prebuilt is st["corr"]
+    assert a._prebuilt[0] is st["corr"] and a._prebuilt[1:] == (f1.data_ptr(), f2.data_ptr())
     n2 = b.encode(*pairs[1])[2]
     assert [t.data_ptr() for t in n2] != [t.data_ptr() for t in b._graph_state["net"]]
     for x, y in zip(net, n2):

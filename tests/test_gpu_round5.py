@@ -177,3 +177,103 @@ def test_bench_two_ranks_over_gloo_on_one_device(tmp_path):
     assert len(j["per_rank_pairs_per_s"]) == 2 and all(v > 0 for v in j["per_rank_pairs_per_s"])
     assert j["config"]["per_gpu_batch"] == 2 and j["gathered_batch"] == 4
     assert abs(j["value"] - 2 * 2 * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"])) <= 1e-6 * j["value"]
+
+
+# ---- reduced-pass convolutions (dkt_conv_c8_desc.passes / dkt_gru_c8_desc.passes): the arithmetic they are DEFINED to be -----------
+def _f16r(x):
+    return x.half().float()
+
+
+def _w_hi(w):
+    """What the packed image's hi plane holds: fp16 of w * 2^e (max |w * 2^e| in [2^12, 2^13)), back at w's scale."""
+    import math
+    e = 12 - math.floor(math.log2(float(w.abs().max())))
+    return (w * 2.0 ** e).half().float() * 2.0 ** -e
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("passes", [1, 2])
+@pytest.mark.parametrize("case", [(1, [128, 64, 64], 256, 72, 100, 1), (2, [128], 128, 50, 70, 2), (1, [64, 64], 64, 37, 45, 3),
+                                  (1, [128, 128, 128], 64, 23, 39, 4), (3, [32], 64, 16, 33, 4)])
+def test_conv_c8_reduced_passes_are_the_rounded_operand_convolution(case, passes):
+    """passes = 2 is the fp32-class convolution of activations ROUNDED to fp16; passes = 1 additionally rounds the weights (their
+    hi plane).  Against fp64 convolutions of exactly those operands the result must be in the split-fp16 class (3e-6): a
+    fragment read too early or a mis-counted wait in the reduced-pass steps would not be."""
+    import torch.nn.functional as F
+    from dkt_stereo_amd import conv_c8 as c8
+    B, chans, cout, H, W, cfg = case
+    torch.manual_seed(cout + H + passes)
+    layer = torch.nn.Conv2d(sum(chans), cout, 3, padding=1).to(DEV)
+    xs = [torch.randn(B, c, H, W, device=DEV) for c in chans]
+    with c8.passes(passes):
+        got = c8.conv2d_c8([c8.pack(x) for x in xs], layer, relu=False, cfg=cfg)
+    x = torch.cat([_f16r(t) for t in xs], 1).double()
+    w = (_w_hi(layer.weight) if passes == 1 else layer.weight).double()
+    want = F.conv2d(x, w, layer.bias.double(), padding=1)
+    full = F.conv2d(torch.cat(xs, 1).double(), layer.weight.double(), layer.bias.double(), padding=1)
+    rel = float((got.double() - want).abs().max() / want.abs().max())
+    off = float((got.double() - full).abs().max() / full.abs().max())
+    print("passes %d cfg %d: vs rounded-operand fp64 %.2e, vs the exact convolution %.2e" % (passes, cfg, rel, off))
+    assert rel <= 3e-6
+    assert off >= 1e-5        # (and it IS the reduced arithmetic: the full product would sit at 1e-6)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("passes", [1, 2])
+@pytest.mark.parametrize("B,H,W,xch", [(1, 96, 160, [128, 128]), (1, 46, 78, [128]), (2, 184, 312, [128, 128])])
+def test_fused_gru_reduced_passes(B, H, W, xch, passes):
+    """The one-launch ConvGRU step at 1 / 2 passes against its fp64 definition on the rounded operands (r*h is rounded where it
+    is stored: the q convolution reads its hi plane), and bit-reproducible launch after launch."""
+    import torch.nn.functional as F
+    from test_gpu_round4 import _State, _make
+    from dkt_stereo_amd import conv_c8 as c8
+    gru, h, xs, cz, cr, cq = _make(B, H, W, xch, seed=H + passes)
+    st = _State(gru, h, xs, cz, cr, cq)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    with c8.passes(passes):
+        d = st.desc()
+    assert c8.gru_launch(d, err=err)
+    p = {k: v.double() for k, v in gru.state_dict().items()}
+    rw = (lambda w: _w_hi(w.float()).double()) if passes == 1 else (lambda w: w)
+    x = torch.cat([_f16r(t) for t in xs], 1).double()
+    hh = _f16r(h).double()
+    hx = torch.cat([hh, x], 1)
+    z = torch.sigmoid(F.conv2d(hx, rw(p["convz.weight"]), p["convz.bias"], padding=1) + cz.double())
+    r = torch.sigmoid(F.conv2d(hx, rw(p["convr.weight"]), p["convr.bias"], padding=1) + cr.double())
+    rh = _f16r((r.float() * h)).double()
+    q = torch.tanh(F.conv2d(torch.cat([rh, x], 1), rw(p["convq.weight"]), p["convq.bias"], padding=1) + cq.double())
+    want = (1 - z) * h.double() + z * q
+    rel = float((st.h.double() - want).abs().max() / want.abs().max())
+    print("gru passes %d: %.2e" % (passes, rel))
+    # (r*h is rounded from the kernel's own fp32 r, which differs from the fp64 one in the last bits: an fp16 rounding boundary
+    # crossed here and there moves single q inputs by 2^-11 relative -- hence the looser bound)
+    assert rel <= 2e-4 and int(err.item()) == 0
+    st2 = _State(gru, h, xs, cz, cr, cq)
+    with c8.passes(passes):
+        assert c8.gru_launch(st2.desc(), err=err)
+    assert torch.equal(st2.h, st.h)
+
+
+@torch.no_grad()
+def test_precision_schedule_runs_and_default_is_untouched(golden):
+    """A (k1, k2) schedule replays units of three kinds from their own captured graphs and lands near the fp32-class result; with the
+    schedule removed the model is bit for bit the parity path again."""
+    c = _cases.E2E_CASES["256x512_it32"]
+    model, _ = _raft()
+    i1, i2 = (G(t) for t in _synth.image_pair(c["seed"], 1, c["H"], c["W"], c["shift"]))
+    model.precision_schedule = None
+    _, ref = model(i1, i2, iters=c["iters"], test_mode=True)
+    model.precision_schedule = (12, 8)
+    _, a = model(i1, i2, iters=c["iters"], test_mode=True)
+    _, b = model(i1, i2, iters=c["iters"], test_mode=True)
+    lp = model._graph_state["c8"]
+    assert torch.equal(a, b) and {k[0] for k in lp.graph} == {1, 2, 3}
+    d = maxabs(a, ref)
+    print("schedule (12, 8) vs fp32-class: %.3e" % d)
+    assert 0 < d <= 5e-2
+    model.precision_schedule = None
+    _, again = model(i1, i2, iters=c["iters"], test_mode=True)
+    assert torch.equal(again, ref)
+    g = golden("raft_e2e")
+    s = int(g["256x512_it32/stride"])
+    assert maxabs(again[:, :, ::s, ::s], g["256x512_it32/flow_up"]) <= 1e-3

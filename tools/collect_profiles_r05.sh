@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round 5 evidence on a GPU box -> gpurun_out/ (copy what is to be kept into profiles/):  bash tools/collect_profiles_r05.sh [steps...]
+# steps: tests prof bench b8 trace stress pmc sched   (default: tests prof bench b8 trace)
+R=r05
+O=gpurun_out
+STEPS=${@:-tests prof bench b8 trace}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && export PYTHONPATH=$GRAFT_REPO_ROOT
+F='^(RCCL|HIP|ROCm) version|^Hostname|^Librccl|amdgpu.ids'
+for s in $STEPS; do case $s in
+tests) timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | grep -v -E "$F" | tail -15 > $O/${R}_gputests.txt ;;
+prof)
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof -o bench -- python bench.py --steps 3 --warmup 2 --skip-cpu-baseline > $O/${R}_prof_bench.log 2>&1
+  T=$(find $O/${R}_prof -name "*kernel_trace.csv" | head -1)
+  python tools/rocprof_pair_breakdown.py $T --pair 6 --phases --timeline 10 --encoders > $O/${R}_pair_breakdown.txt 2>&1
+  python tools/rocprof_summary.py $T > $O/${R}_kernels.txt 2>&1
+  cp $(find $O/${R}_prof -name "*kernel_stats.csv" | head -1) $O/${R}_bench_kernel_stats.csv
+  rm -rf $O/${R}_prof ;;
+bench) timeout 900 python bench.py --steps 20 --warmup 3 2>$O/${R}_bench_b1.err | tail -1 > $O/${R}_bench_b1.json ;;
+b8) timeout 900 python bench.py --steps 5 --warmup 2 --batch 8 --skip-cpu-baseline 2>$O/${R}_bench_b8.err | tail -1 > $O/${R}_bench_b8.json ;;
+trace) timeout 600 python tools/gru_c8_trace.py --batch=1 --batch=8 2>&1 | grep -v amdgpu > $O/${R}_gru_c8_phases.txt ;;
+stress) timeout 1500 python tools/stress_forward.py 1000 2>&1 | grep -v amdgpu > $O/${R}_stress_forward.txt ;;
+pmc) bash tools/pmc/run_pmc_r05.sh 1 > $O/${R}_pmc.log 2>&1; python tools/pmc/make_traffic_r05.py $O/r05_pmc 1 --profiles >> $O/${R}_pmc.log 2>&1 ;;
+sched) timeout 2400 python tools/precision_schedule.py 2>&1 | grep -v amdgpu > $O/${R}_precision_schedule.txt ;;
+esac; done
+ls -la $O | tail -20

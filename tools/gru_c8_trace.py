@@ -21,8 +21,19 @@ def build(subs, trace=True):
     src = open(os.path.join(B.CSRC, "gru_c8.hip")).read()
     if trace:
         import re
+        # one record of 8 time stamps per (tile round of the block, block); later tiles of a block restart at stamp 0 behind
+        # the previous tile's gate B (their "prologue" = the context terms + first fragments)
         src = re.sub(r"// @trace\((\d+)\)",
-                     r"if (tid == 0) ((unsigned long long *)(ap.err + 16))[blockIdx.x * 8 + \1] = __builtin_amdgcn_s_memrealtime();", src)
+                     r"if (tid == 0) ((unsigned long long *)(ap.err + 16))[(trace_round * gridDim.x + blockIdx.x) * 8 + \1] = __builtin_amdgcn_s_memrealtime();", src)
+        a = "    const int tid = threadIdx.x;\n"
+        assert a in src
+        src = src.replace(a, a + "    int trace_round = 0;\n", 1)
+        a = "        tile = tn; b = nb; txy = ntxy; h0 = nh0; w0 = nw0;\n"
+        assert a in src
+        src = src.replace(a, a + "        ++trace_round;\n        if (tid == 0) ((unsigned long long *)(ap.err + 16))[(trace_round * gridDim.x + blockIdx.x) * 8 + 0] = __builtin_amdgcn_s_memrealtime();\n", 1)
+        a = "        init_A(b, h0, w0);\n        G8_FIRST_FRAGS(2)\n    }\n"
+        assert a in src
+        src = src.replace(a, "        init_A(b, h0, w0);\n        G8_FIRST_FRAGS(2)\n        if (tid == 0) ((unsigned long long *)(ap.err + 16))[(trace_round * gridDim.x + blockIdx.x) * 8 + 1] = __builtin_amdgcn_s_memrealtime();\n    }\n", 1)
     for sub in subs:
         a, b = sub.split("=>")
         assert a in src, a
@@ -38,30 +49,45 @@ def build(subs, trace=True):
     return lib
 
 
-def run(lib, pair=True, reps=300):
+def run(lib, pair=True, reps=300, B=1):
     os.environ["DKT_LIB_PATH"] = lib
     from dkt_stereo_amd import conv_c8 as c8
     sys.path.insert(0, HERE)
     import gru_c8_check as chk
-    big = chk.State(*chk.make(1, 184, 312, [128, 128], 1))
-    small = chk.State(*chk.make(1, 23, 39, [128], 2))
-    err = torch.zeros(16 + 2 * 8 * 300, device="cuda", dtype=torch.int32)
+    big = chk.State(*chk.make(B, 184, 312, [128, 128], 1))
+    small = chk.State(*chk.make(B, 46, 78, [128], 2))          # the loop's rider: gru32 at 1/16 resolution
+    rounds = 12
+    err = torch.zeros(16 + 2 * 8 * 256 * rounds, device="cuda", dtype=torch.int32)
     d0, d1 = big.desc(), small.desc()
+    reps = max(3, reps // B)
     for _ in range(reps):
+        err[16:].zero_()
         c8.gru_launch(d0, d1 if pair else None, err=err)
     torch.cuda.synchronize()
-    t = err[16:].view(torch.int64).view(-1, 8)[:248 if pair else 230].cpu().double() * 0.01       # us
+    t_all = err[16:].view(torch.int64).view(rounds, 256, 8).cpu().double() * 0.01       # us; [round][block][stamp]
+    nblk = int((t_all[0, :, 0] > 0).sum())
     names = ["prologue", "phase A", "gate A + publish", "phase B", "gate B"]
-    t = t[t[:, 0] > 0]
-    t0 = t[:, 0].min()
-    print("blocks %d; kernel span %.1f us (first start -> last end)" % (t.shape[0], float(t[:, 5].max() - t0)))
-    print("start skew: %.1f us" % float(t[:, 0].max() - t0))
-    for k, n in enumerate(names):
-        d = t[:230, k + 1] - t[:230, k]
-        print("  %-18s median %.1f  min %.1f  max %.1f us" % (n, float(d.median()), float(d.min()), float(d.max())))
-    for k, n in ((2, "end of phase A"), (3, "published"), (4, "end of phase B"), (5, "done")):
-        d = t[:230, k] - t0
-        print("  %-18s at median %.1f  min %.1f  max %.1f us" % (n, float(d.median()), float(d.min()), float(d.max())))
+    t0 = t_all[0, :nblk, 0].min()
+    last = t_all[:, :, 5].max()
+    print("batch %d: blocks %d; kernel span %.1f us (first start -> last end)" % (B, nblk, float(last - t0)))
+    print("start skew: %.1f us" % float(t_all[0, :nblk, 0].max() - t0))
+    # blocks of the finest level (problem 0) only: the rider's blocks are the launch's last ones
+    tiles0 = B * 230
+    nb0 = nblk if not pair else (nblk - min(18 * B, max(1, round(nblk * (18 * B * 32.0) / (tiles0 * 48.0 + 18 * B * 32.0)))) if tiles0 + 18 * B > nblk else tiles0)
+    for r in range(rounds):
+        t = t_all[r, :nb0]
+        t = t[(t[:, 0] > 0) & (t[:, 5] > 0)]
+        if t.shape[0] == 0:
+            break
+        print("round %d: %d tiles, start at median %.1f us, done at median %.1f (max %.1f)" %
+              (r, t.shape[0], float((t[:, 0] - t0).median()), float((t[:, 5] - t0).median()), float((t[:, 5] - t0).max())))
+        for k, n in enumerate(names):
+            d = t[:, k + 1] - t[:, k]
+            print("  %-18s median %.1f  min %.1f  max %.1f us" % (n, float(d.median()), float(d.min()), float(d.max())))
+        if r == 0:
+            for k, n in ((2, "end of phase A"), (3, "published"), (4, "end of phase B"), (5, "done")):
+                d = t[:, k] - t0
+                print("  %-18s at median %.1f  min %.1f  max %.1f us" % (n, float(d.median()), float(d.min()), float(d.max())))
     print("err word", int(err[0].item()))
 
 
@@ -73,4 +99,6 @@ if __name__ == "__main__":
         lib = os.path.join(OUT, "libdktstereo_trace.so")
         if not os.path.exists(lib) or "--rebuild" in sys.argv:
             lib = build(subs)
-        run(lib, pair="--single" not in sys.argv)
+        bs = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--batch=")] or [1]
+        for B_ in bs:
+            run(lib, pair="--single" not in sys.argv, B=B_)
