@@ -202,7 +202,7 @@ class C8Loop:
         """One captured unit per entry of `plan` (its MFMA passes); `last`: the final entry is the pair's final unit."""
         plan = list(plan)
         for p in sorted(set(plan)):
-            if (p, 0) not in self.graph:
+            if self.graph is None or (p, 0) not in self.graph:
                 self.capture(st, capture_graph, p)          # (first use of this kind of unit: once per state)
         tail = plan.pop() if last else None
         step = GRAPH_UNITS if GRAPH_UNITS % 2 == 0 or not self.front else 0      # (an odd run of units would end on the other parity)
