@@ -64,6 +64,9 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend for --gpus > 1: nccl = RCCL over xGMI (default); gloo = host-staged, lets several "
                         "ranks share one device (tests/test_gpu_round5.py exercises the N > 1 branch that way on a 1-GPU box)")
+    p.add_argument("--schedule", default=None, metavar="K1,K2",
+                   help="precision schedule of the refinement loop (loop_c8.SCHEDULE): the first K1 iterations at one fp16 MFMA product "
+                        "per block, the next K2 at two, the rest fp32-class.  A SEPARATE line, never the headline: `dtype` says what ran")
     p.add_argument("--conv-backend", default=None, choices=["f16x3", "f16x2", "f16", "miopen"],
                    help="update-block convolution path (default: the package default, f16x3)")
     a = p.parse_args()
@@ -195,6 +198,13 @@ def main():
                          "f16x2": "hip split-fp16 MFMA x2", "f16": "hip fp16 MFMA",
                          "miopen": "miopen-fp32"}[_conv.get_backend()]
     model = RAFTStereo()
+    schedule = None
+    if args.schedule:
+        k = [int(x) for x in args.schedule.split(",")]
+        schedule = (k[0], k[1] if len(k) > 1 else 0)
+        if sum(schedule) > args.iters or min(schedule) < 0:
+            raise SystemExit("--schedule: K1 + K2 must not exceed --iters")
+    model.precision_schedule = schedule if (schedule and sum(schedule)) else None
     sd = _synth.torch_state_dict(_synth.shapes_of(model), 7)
     model.load_state_dict(sd, strict=True)
     model.to(dev).eval()
@@ -459,6 +469,8 @@ def main():
     alg = lookup_bytes_per_launch(n_pix, cout=64 if fused_lookup else None)
     achieved = alg / (look_avg_ms * 1e-3) / 1e9 if look_avg_ms > 0 else 0.0
     passes = {"f16x3": 3, "f16x2": 2, "f16": 1}.get(_conv.get_backend(), 1)
+    if model.precision_schedule:        # (average MFMA products per block over the timed launches of a scheduled loop)
+        passes = (schedule[0] + 2 * schedule[1] + 3 * (args.iters - sum(schedule))) / float(args.iters)
     conv_avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
     conv_alg_flops = 2.0 * n_pix * 384 * 9 * 256
     conv_kernel = "conv2d_f16s_kernel (dkt_conv2d_f16s_gate_zr), gru08 z|r 384->256 3x3 + gate epilogue @%dx%d" % (h4, w4)
@@ -509,11 +521,19 @@ def main():
         "vs_baseline": None,
         # the arithmetic type of the path, not a precision claim: tensors and accumulation are fp32, every product of the
         # convolutions is evaluated on the fp16 matrix pipe from split operands (see "precision")
-        "dtype": {"f16x3": "f32 io/accumulate; convolution products = 3x fp16-split MFMA (22-bit operands); lookup / correlation exact fp32",
+        "dtype": ("f32 io/accumulate; REDUCED-PRECISION SCHEDULE (not the headline): refinement iterations 1..%d with weights and activations "
+                  "rounded to fp16 (1 MFMA product), %d..%d with activations rounded to fp16 (2 products), %d..%d fp32-class (3 products); "
+                  "encoders, correlation volume, lookup, up-sampling fp32-class / exact fp32"
+                  % (schedule[0], schedule[0] + 1, schedule[0] + schedule[1], schedule[0] + schedule[1] + 1, args.iters))
+                 if model.precision_schedule else
+                 {"f16x3": "f32 io/accumulate; convolution products = 3x fp16-split MFMA (22-bit operands); lookup / correlation exact fp32",
                   "f16x2": "f32 io/accumulate; convolution products = 2x fp16-split MFMA (NOT a parity path)",
                   "f16": "f32 io/accumulate; convolution products = fp16 MFMA (NOT a parity path)",
                   "miopen": "f32 (vendor fp32 convolutions)"}[_conv.get_backend()],
         "precision": precision,
+        "precision_schedule": ({"one_pass_iterations": schedule[0], "two_pass_iterations": schedule[1],
+                                "note": "errors against the reference fixtures per schedule: profiles/r05_precision_schedule.txt"}
+                               if model.precision_schedule else None),
         "data": "synthetic (seeded U[0,255) left image, shifted+noised right image; random-init weights)",
         "config": {"workload": "RAFT-Stereo %dx%d (1/4 res %dx%d), D=192, %d GRU iters, batch %d/GPU, "
                                "corr_implementation=reg, BASELINE.json configs[1]"

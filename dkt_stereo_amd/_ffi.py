@@ -119,6 +119,9 @@ SIGNATURES = {
     "dkt_conv_c8_pack_weights": [_vp, _ip, _i, _i, _f, _vp, _i, _vp],
     "dkt_conv2d_c8": [ctypes.POINTER(ConvC8Desc), _i, _i, _vp],
     "dkt_conv2d_c8_pair": [ctypes.POINTER(ConvC8Desc), ctypes.POINTER(ConvC8Desc), _i, _i, _vp],
+    "dkt_conv2d_c8_chain": [ctypes.POINTER(ConvC8Desc), ctypes.POINTER(ConvC8Desc), _i, ctypes.POINTER(ConvC8Desc), _i, _vp, _vp, _i, _i,
+                            _i, _vp],
+    "dkt_conv2d_c8_chain_flag_words": [ctypes.POINTER(ConvC8Desc), _i, _i],
     "dkt_conv2d_f16s_pair": [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _i, _i, _vp],
     "dkt_conv2d_f16s_desc": [ctypes.POINTER(ConvDesc), _i, _i, _vp],
     "dkt_corr1d_build": [_vp, _vp, _pp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -173,7 +176,7 @@ SIGNATURES = {
     "dkt_interp_bilinear": [_vp, _vp, _l, _i, _i, _i, _i, _i, _vp],
 }
 #: entry points that do not return an int status
-RESTYPES = {"dkt_gru_c8_flag_words": ctypes.c_long, "dkt_conv2d_stats_ws_floats": ctypes.c_long, "dkt_conv_c8_packed_bytes": ctypes.c_long, "dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
+RESTYPES = {"dkt_gru_c8_flag_words": ctypes.c_long, "dkt_conv2d_c8_chain_flag_words": ctypes.c_long, "dkt_conv2d_stats_ws_floats": ctypes.c_long, "dkt_conv_c8_packed_bytes": ctypes.c_long, "dkt_conv2d_packed_elems": ctypes.c_long, "dkt_conv2d_stem7_packed_elems": ctypes.c_long, "dkt_instance_norm_workspace": ctypes.c_long}
 
 #: DKT_E_UNSUPPORTED of include/dktstereo.h
 E_UNSUPPORTED = -7

@@ -410,6 +410,30 @@ def launch_pair(d0, d1, ref, cfg):
     _ffi.check(rc, "dkt_conv2d_c8_pair")
 
 
+def chain_flags(d0, cfg0, nprob, device):
+    """The flag words of one dkt_conv2d_c8_chain pair of layers (zero-initialised; every launch increments them)."""
+    n = int(_ffi.lib().dkt_conv2d_c8_chain_flag_words(ctypes.byref(d0), cfg0, nprob))
+    if n <= 0:
+        raise _ffi.DktError("dkt_conv2d_c8_chain_flag_words rejected the stage")
+    return torch.zeros(n, device=device, dtype=torch.int32)
+
+
+def launch_chain(d0a, d0b, cfg0, d1, cfg1, flags, ref, err=None, max_blocks=0, timing_only=False):
+    """Two dependent layers in one launch (dkt_conv2d_c8_chain): stage 0 = d0a [| d0b], stage 1 = d1 reading stage 0's
+    C8S output behind a flag round.  Returns False when the shapes are not covered (the caller launches them one by one)."""
+    p = max(d.passes for d in (d0a, d0b, d1) if d is not None)
+    for d in (d0a, d0b, d1):
+        if d is not None:
+            d.passes = p
+    rc = _ffi.lib().dkt_conv2d_c8_chain(ctypes.byref(d0a), None if d0b is None else ctypes.byref(d0b), cfg0, ctypes.byref(d1), cfg1,
+                                        flags.data_ptr(), None if err is None else err.data_ptr(), max_blocks, int(bool(timing_only)),
+                                        _ffi.device_of(ref), _ffi.stream_of(ref))
+    if rc == _ffi.E_UNSUPPORTED:
+        return False
+    _ffi.check(rc, "dkt_conv2d_c8_chain")
+    return True
+
+
 def conv2d_c8(srcs, layer, relu=False, out=None, out_c8=None, out_c8_ch0=0, tail=None, cfg=0):
     """conv(torch.cat(srcs)) + bias [ReLU] -> fp32 NCHW `out` (allocated when neither destination is given) and / or
     channels [out_c8_ch0, ...) of the ActC8 `out_c8`; `tail`: fp32 NCHW channels appended behind the result in

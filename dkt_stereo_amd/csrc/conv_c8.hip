@@ -66,6 +66,21 @@ struct C8ArgsPair {
     C8Args p[2];
 };
 
+// Flag round between the two stages of conv_c8_chain_kernel (gru_c8.hip's protocol): a stage-0 tile publishes its flag word
+// (launch count) behind an agent-scope release of its stores; a stage-1 tile waits, before its first patch is requested, for the
+// stage-0 tiles that produce the patch rows and columns it reads (its own tile, the halo, every channel block, both problems).
+// pub / dep null: plain launch.
+struct C8Sync {
+    unsigned *pub;              // [problem][tile] words of the stage that publishes
+    const unsigned *dep;        // ... the same words, as the stage that waits sees them
+    int dep_tr;                 // rows per tile of the publishing stage
+    int dep_tiles_w, dep_tiles_h, dep_nco, dep_nprob;      // its tile grid, channel blocks and problems
+    int dep_tiles_per_prob;     // tiles_xy * n_co * B of one publishing problem
+    unsigned *err;
+    unsigned target;            // the launch count this launch publishes (set by the kernel from the block's own first word)
+    int timing_only;            // 1: no waits at all (an upper bound of what the fusion can buy; results are wrong)
+};
+
 __device__ __forceinline__ float c8_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float c8_tanh(float x) {
     const float xc = x < -15.0f ? -15.0f : (x > 15.0f ? 15.0f : x);      // NaN passes through
@@ -105,8 +120,12 @@ __device__ __forceinline__ void c8_wait_lgkm() {
 // never read); 1 = w_hi*x_hi only (plain fp16 operands).  Reduced-pass launches are NOT parity paths by themselves: they serve the
 // precision schedules of loop_c8 (early refinement iterations at fewer passes).  The DMA stream, the ring and the
 // vmcnt waits are the same in all three; what changes is which fragments are read and multiplied (and the lgkmcnt counts).
-template <int WM, int WN, int NF, int RING, int PASSES = 3>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_kernel(C8ArgsPair ap, int nb0) {
+// The kernel's body as a device function (round 5): `nblocks` persistent blocks, this one `bid`, walk the tiles of the launch's
+// one or two problems; `lds` = the block's dynamic LDS.  conv_c8_kernel is this body; conv_c8_chain_kernel runs two of them
+// back to back in one launch (dependent layers with a flag round instead of a kernel boundary, see C8Sync).
+template <int WM, int WN, int NF, int RING, int PASSES>
+__device__ __forceinline__ void conv_c8_body(const C8ArgsPair &ap, const int nb0, const int nblocks, const int bid, char *const lds,
+                                             const C8Sync &sy) {
     static_assert(PASSES >= 1 && PASSES <= 3, "passes");
     constexpr int C8_RING = RING;
     constexpr int NW = WM * WN;
@@ -122,14 +141,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
     constexpr int WPI = (WM * 4) / NW;               // weight DMA pieces per wave and step
     static_assert((WM * 4) % NW == 0, "weight image must split evenly over the waves");
     constexpr int MF = 2;
-    extern __shared__ __attribute__((aligned(16))) char lds[];       // act[2][ACT_BYTES] | wring[C8_RING][WSLOT]
-    char *const lds_act = lds;
+    char *const lds_act = lds;                       // act[2][ACT_BYTES] | wring[C8_RING][WSLOT]
     char *const lds_w = lds + 2 * ACT_BYTES;
 
-    const bool second = (int)blockIdx.x >= nb0;
+    const bool second = bid >= nb0;
     const C8Args &a = ap.p[second ? 1 : 0];
     const int blk_first = second ? nb0 : 0;
-    const int blk_count = second ? (int)gridDim.x - nb0 : nb0;
+    const int blk_count = second ? nblocks - nb0 : nb0;
+    if (bid - blk_first >= a.total_tiles || blk_count <= 0) return;      // (a chain stage with fewer tiles than the launch has blocks)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -146,8 +165,50 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         tb = r / a.n_co;
     };
     int h0, w0, co_blk, b;
-    int tile = (int)blockIdx.x - blk_first;
+    int tile = bid - blk_first;
     decode(tile, h0, w0, co_blk, b);
+
+    // ---- chain launches (C8Sync): wave 0 polls the flags of the stage-0 tiles a stage-1 tile reads from
+    typedef __attribute__((address_space(1))) unsigned c8_gu32;
+    auto wait_deps = [&](int th0, int tw0, int tb) {
+        if (!sy.dep || sy.timing_only) return;
+        if (wave == 0) {
+            const int r0 = (th0 > 0 ? th0 - 1 : 0) / sy.dep_tr;
+            int r1 = (th0 + TR) / sy.dep_tr;
+            r1 = r1 < sy.dep_tiles_h ? r1 : sy.dep_tiles_h - 1;
+            const int c0 = tw0 / 32 > 0 ? tw0 / 32 - 1 : 0;
+            int c1 = tw0 / 32 + 1;
+            c1 = c1 < sy.dep_tiles_w ? c1 : sy.dep_tiles_w - 1;
+            const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;
+            const int per = nr * nc, n = per * sy.dep_nco * sy.dep_nprob;          // <= 64 (checked by the host)
+            int k = lane < n ? lane : 0;
+            const int cc = k % nc; k /= nc;
+            const int rr = k % nr; k /= nr;
+            const int co = k % sy.dep_nco, pr = k / sy.dep_nco;
+            const long idx = (long)pr * sy.dep_tiles_per_prob +
+                             ((long)tb * sy.dep_nco + co) * (sy.dep_tiles_w * sy.dep_tiles_h) + (r0 + rr) * sy.dep_tiles_w + (c0 + cc);
+            c8_gu32 *f = (c8_gu32 *)sy.dep + idx;
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = lane >= n || (int)(v - sy.target) >= 0;
+                if (__all(ok)) break;
+                if (spins > (1u << 21)) {
+                    if (lane == 0 && sy.err) __hip_atomic_store((c8_gu32 *)sy.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    };
+    auto publish = [&](int t) {
+        if (!sy.pub || sy.timing_only) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wave: its stores of this tile are visible device-wide
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0)
+            __hip_atomic_store((c8_gu32 *)sy.pub + (long)(second ? sy.dep_tiles_per_prob : 0) + t, sy.target, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    };
 
     // ---- activation DMA: piece p = j * NW + wave covers units u = 64 p + lane of the chunk image
     //      [q = 2 kg + hl][patch pixel]; the source offset of a lane inside the chunk's 4 planes is fixed per tile.
@@ -466,6 +527,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
     // main stream
     // ------------------------------------------------------------------------------------------------
     tile_offsets(h0, w0, aoff_cur);
+    if (sy.dep) {
+        wait_deps(h0, w0, b);
+        __builtin_amdgcn_s_barrier();
+    }
     // prologue: chunk 0's patch and the weight images of steps 0..2
     issue_act(chunk_base(b, 0), aoff_cur, 0);
     const char *wptr = w_tile(co_blk);          // image of the next step to fetch
@@ -513,7 +578,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
             const int c_f = in_tile ? (c) + 1 : (have_next ? 0 : (c));                                            \
             const char *w_next = w_tile(have_next ? nco : co_blk);                                                \
             const int b_f = in_tile ? b : nb;                                                                     \
-            if (!in_tile && have_next) tile_offsets(nh0, nw0, aoff_nxt);                                          \
+            if (!in_tile && have_next) {                                                                          \
+                tile_offsets(nh0, nw0, aoff_nxt);                                                                 \
+                wait_deps(nh0, nw0, nb);      /* (before the step barrier that precedes the next tile's first patch request) */ \
+            }                                                                                                     \
             const char *act_f = chunk_base(b_f, c_f);                                                             \
             const int cur = g & 1, nxt = cur ^ 1;
             // One (chunk, tap) step.  Steps run tap COLUMN by column (dx outer, dy inner: the weight images are packed in
@@ -689,6 +757,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         }
         c8_wait_lgkm<0>();      // the prefetched fragments of the next tile have landed: their registers are stable
         epilogue();
+        publish(tile);
         if (!have_next) break;
         tile = tn; h0 = nh0; w0 = nw0; co_blk = nco; b = nb;
 #pragma unroll
@@ -700,6 +769,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_k
         C8_PRIME(g)
     }
     c8_wait_vm<0>();        // no DMA may land in this block's LDS after it has been released
+}
+
+template <int WM, int WN, int NF, int RING, int PASSES = 3>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void conv_c8_kernel(C8ArgsPair ap, int nb0) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    conv_c8_body<WM, WN, NF, RING, PASSES>(ap, nb0, (int)gridDim.x, (int)blockIdx.x, lds, C8Sync{});
+}
+
+// Two dependent launches as ONE (round 5 prototype): stage 0 (shape 0, one or two problems) and stage 1 (shape 1, one
+// problem that reads what stage 0 writes), both of 4-wave blocks.  Every block walks its stage-0 tiles, then its stage-1 tiles.
+template <int WN0, int NF0, int RING0, int WN1, int NF1, int RING1, int PASSES>
+__global__ __launch_bounds__(256, 2) void conv_c8_chain_kernel(C8ArgsPair s0, int nb0_0, C8ArgsPair s1, C8Sync sy) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // the flag words count launches: every word holds the same value before a launch, and a block's own first stage-0 tile is
+    // written by nobody else -- its old value + 1 is what this launch publishes everywhere
+    if (sy.pub) {
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        const long own = (int)blockIdx.x < nb0_0 ? (long)blockIdx.x : (long)sy.dep_tiles_per_prob + ((long)blockIdx.x - nb0_0);
+        sy.target = __builtin_amdgcn_readfirstlane(__hip_atomic_load((gu32 *)sy.pub + own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u);
+    }
+    C8Sync p = sy;
+    p.dep = nullptr;                                   // stage 0 publishes, waits for nothing
+    conv_c8_body<1, WN0, NF0, RING0, PASSES>(s0, nb0_0, (int)gridDim.x, (int)blockIdx.x, lds, p);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // the LDS changes hands
+    C8Sync c = sy;
+    c.pub = nullptr;                                   // stage 1 waits, publishes nothing
+    conv_c8_body<1, WN1, NF1, RING1, PASSES>(s1, (int)gridDim.x, (int)gridDim.x, (int)blockIdx.x, lds, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1015,6 +1112,107 @@ extern "C" int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_
     if ((d0->passes ? d0->passes : 3) != (d1->passes ? d1->passes : 3)) return DKT_E_UNSUPPORTED;
     DKT_ENTER(device);
     return c8_dispatch(a, d0->B, cfg, d0->passes, (hipStream_t)stream, &b, d1->B);
+}
+
+// ---- chain launch: stage 0 (d0a [, d0b]) -> stage 1 (d1), one launch, a flag round instead of the kernel boundary
+template <int WN0, int NF0, int RING0, int WN1, int NF1, int RING1, int PASSES>
+static int c8_chain_launch(C8Args a0, const C8Args *b0, int B, C8Args a1, C8Sync sy, int max_blocks, hipStream_t st) {
+    constexpr int TR0 = WN0 * NF0, TR1 = WN1 * NF1;
+    auto lds_of = [](int TR, int RING) -> size_t {
+        const int NU = (TR + 2) * C8_PC * 4, NPR = (NU + 63) / 64, NIA = (NPR + 3) / 4;
+        return (size_t)2 * (NIA * 4 > NPR ? NPR + 1 : NPR) * 1024 + (size_t)RING * 4096;
+    };
+    const size_t l0 = lds_of(TR0, RING0), l1 = lds_of(TR1, RING1), lds = l0 > l1 ? l0 : l1;
+    auto kern = conv_c8_chain_kernel<WN0, NF0, RING0, WN1, NF1, RING1, PASSES>;
+    static int slots[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!slots[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu < 1) return DKT_E_UNSUPPORTED;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return DKT_E_UNSUPPORTED;
+        slots[dev & 63] = per_cu * cus;
+    }
+    auto shape = [&](C8Args &x, int TR) -> long {
+        x.tiles_w = (x.W + 31) / 32;
+        x.tiles_xy = x.tiles_w * ((x.H + TR - 1) / TR);
+        x.n_co = x.n_co64;                              // WM = 1
+        const long total = (long)x.tiles_xy * x.n_co * B;
+        x.total_tiles = (int)total;
+        return total;
+    };
+    C8ArgsPair s0, s1;
+    const long t0a = shape(a0, TR0);
+    s0.p[0] = a0; s0.p[1] = a0;
+    long t0b = 0;
+    if (b0) {
+        C8Args b = *b0;
+        t0b = shape(b, TR0);
+        if (t0b != t0a) return DKT_E_UNSUPPORTED;       // (the flag words of the two problems are indexed alike)
+        s0.p[1] = b;
+    }
+    const long t1 = shape(a1, TR1);
+    s1.p[0] = a1; s1.p[1] = a1;
+    if (t0a + t0b > 0x7fffffffL || t1 > 0x7fffffffL) return DKT_E_SHAPE;
+    // Every block must be resident while it may wait: the grid never exceeds what the device holds of this kernel, nor
+    // max_blocks (two chains on two streams must fit TOGETHER), nor the stage-0 tiles (a block takes the launch
+    // count from a stage-0 tile of its own)
+    long cap = slots[dev & 63];
+    if (max_blocks > 0 && max_blocks < cap) cap = max_blocks;
+    long grid = t0a + t0b < cap ? t0a + t0b : cap;
+    long nb0 = b0 ? (long)(grid * ((double)t0a * a0.nchunks / ((double)t0a * a0.nchunks + (double)t0b * b0->nchunks)) + 0.5) : grid;
+    if (b0) {
+        nb0 = nb0 < 1 ? 1 : (nb0 > grid - 1 ? grid - 1 : nb0);
+        if (nb0 > t0a) nb0 = t0a;
+        if (grid - nb0 > t0b) grid = nb0 + t0b;
+    }
+    sy.dep_tr = TR0;
+    sy.dep_tiles_w = a0.tiles_w; sy.dep_tiles_h = a0.tiles_xy / a0.tiles_w; sy.dep_nco = a0.n_co; sy.dep_nprob = b0 ? 2 : 1;
+    sy.dep_tiles_per_prob = (int)t0a;
+    sy.target = 0;
+    // flags a stage-1 tile polls: (rows) x 3 columns x channel blocks x problems on the 64 lanes of one wave
+    const int rows = (TR1 + 1) / TR0 + 2;
+    if (rows * 3 * sy.dep_nco * sy.dep_nprob > 64) return DKT_E_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, s0, (int)nb0, s1, sy);
+    return dkt_launch_status();
+}
+
+extern "C" long dkt_conv2d_c8_chain_flag_words(const dkt_conv_c8_desc *d0, int cfg0, int nprob) {
+    if (!d0 || (cfg0 != 3 && cfg0 != 4) || nprob < 1 || nprob > 2) return DKT_E_SHAPE;
+    const int TR = cfg0 == 3 ? 8 : 4;
+    return (long)nprob * ((d0->W + 31) / 32) * ((d0->H + TR - 1) / TR) * ((d0->Cout + 63) / 64) * d0->B;
+}
+
+extern "C" int dkt_conv2d_c8_chain(const dkt_conv_c8_desc *d0a, const dkt_conv_c8_desc *d0b, int cfg0, const dkt_conv_c8_desc *d1,
+                                   int cfg1, unsigned *flags, unsigned *err_word, int max_blocks, int timing_only, int device,
+                                   void *stream) {
+    if (!d0a || !d1 || !flags) return DKT_E_NULL;
+    C8Args a0, b0, a1;
+    int rc = c8_fill(a0, d0a);
+    if (rc != DKT_OK) return rc;
+    if (d0b && (rc = c8_fill(b0, d0b)) != DKT_OK) return rc;
+    if ((rc = c8_fill(a1, d1)) != DKT_OK) return rc;
+    if (d0a->B != d1->B || d0a->H != d1->H || d0a->W != d1->W || (d0b && (d0b->B != d0a->B || d0b->H != d0a->H || d0b->W != d0a->W)))
+        return DKT_E_SHAPE;
+    const int p = d0a->passes ? d0a->passes : 3;
+    if ((d1->passes ? d1->passes : 3) != p || (d0b && (d0b->passes ? d0b->passes : 3) != p)) return DKT_E_UNSUPPORTED;
+    if (p == 1 && ((a0.nchunks & 1) || (a1.nchunks & 1) || (d0b && (b0.nchunks & 1)))) return DKT_E_UNSUPPORTED;
+    if (a0.epi == 3 || a1.epi == 3 || (d0b && b0.epi == 3)) return DKT_E_UNSUPPORTED;
+    C8Sync sy = {};
+    sy.pub = flags; sy.dep = flags; sy.err = err_word; sy.timing_only = timing_only ? 1 : 0;
+    DKT_ENTER(device);
+    hipStream_t st = (hipStream_t)stream;
+    const C8Args *pb = d0b ? &b0 : nullptr;
+#define C8_CHAIN_CASE(P)                                                                                       \
+    if (cfg0 == 4 && cfg1 == 3) return c8_chain_launch<4, 1, 8, 4, 2, 6, P>(a0, pb, d0a->B, a1, sy, max_blocks, st); \
+    if (cfg0 == 4 && cfg1 == 4) return c8_chain_launch<4, 1, 8, 4, 1, 8, P>(a0, pb, d0a->B, a1, sy, max_blocks, st);
+    if (p == 3) { C8_CHAIN_CASE(3) }
+    else if (p == 2) { C8_CHAIN_CASE(2) }
+    else { C8_CHAIN_CASE(1) }
+#undef C8_CHAIN_CASE
+    return DKT_E_UNSUPPORTED;
 }
 
 // ---- second layer of the flow / disparity head from the planes of epilogue 3 (core/update.py:10-13, 3x3, padding 1):

@@ -51,6 +51,13 @@ FRONT = True
 PAIR_RESAMPLE = True
 #: the flow head is the fused GRU launch's first successor in the captured unit (see C8Loop.unit)
 HEAD_FIRST = True
+#: round 5 prototype: dependent layer pairs of the window between two fused-GRU launches as ONE
+#: launch each, a flag round instead of the kernel boundary (dkt_conv2d_c8_chain): convc2 | convf2 -> encoder.conv on the main
+#: queue, the middle GRU's z|r -> q on the forked one.  0 = off (default: measured, profiles/r05_chain.txt), 1 = on,
+#: 2 = timing only (no waits: the upper bound of what the fusion can buy; results are wrong).  Both chains can be in flight at
+#: once, and every block of a chain must stay resident while it waits: CHAIN_BLOCKS each
+CHAIN = int(os.environ.get("DKT_C8_CHAIN", "0"))
+CHAIN_BLOCKS = int(os.environ.get("DKT_C8_CHAIN_BLOCKS", "256"))
 #: units per captured graph: a replay boundary costs ~8 us of idle device between two units (profiles/r04_pair_breakdown.txt), so
 #: the bulk of the iterations is replayed GRAPH_UNITS units at a time (a one-unit graph serves the remainder)
 GRAPH_UNITS = max(1, int(os.environ.get("DKT_C8_GRAPH_UNITS", "8")))
@@ -150,6 +157,8 @@ class C8Loop:
         self.graph_last = None           # [parity] the final unit of a pair
         self.pinned = []                 # packed weight images the captured units point to (see capture)
         self.unit_launches = None
+        self.chain_flags, self.chain_z = {}, {}          # dkt_conv2d_c8_chain: flag words per layer pair, z of the middle GRU
+        self.chain_ok = True
         self.front = bool(FRONT) and self._front_supported(st)
         mask = getattr(ub, "mask", None)               # (IGEV's mask features are computed by its caller)
         self.mask_head = mask if (mask is not None and len(mask) == 3 and isinstance(mask[0], torch.nn.Conv2d)
@@ -303,6 +312,7 @@ class C8Loop:
         """The two-launch form of the finest ConvGRU from here on (after a flag time-out: this device does not keep the
         launch's blocks resident, e.g. another process holds part of the CUs); captured units are dropped."""
         self.fuse_gru = False
+        self.chain_ok = False            # (the chain launches wait on flags the same way)
         self.graph = self.graph_n = self.graph_last = None
         self.pinned = []
         self.par = 0
@@ -323,9 +333,26 @@ class C8Loop:
         return ub.gru08, ub.gru16, ub.gru32
 
     # ---- pieces -------------------------------------------------------------------------------------------------
-    def _gru(self, lvl, gru, st, xs, cfg_zr, cfg_q):
+    def _chain_flags(self, key, d0, cfg0, nprob):
+        f = self.chain_flags.get(key)
+        if f is None:
+            f = self.chain_flags[key] = c8.chain_flags(d0, cfg0, nprob, self.err.device)
+        return f
+
+    def _gru(self, lvl, gru, st, xs, cfg_zr, cfg_q, chain=False):
         h = st["net"][lvl]
         cz, cr, cq = st["inp"][lvl]
+        if chain and CHAIN and self.chain_ok and cfg_zr == 4 and cfg_q == 4:
+            # z|r + gates -> q + state update as ONE launch: a q tile waits for the z|r tiles of its 3x3 neighbourhood (all four
+            # channel blocks: they have read every patch of the old state by then, so the in-place update is safe)
+            z = self.chain_z.get(lvl)
+            if z is None:
+                z = self.chain_z[lvl] = torch.empty_like(h)
+            d0 = c8.desc([self.hc8[lvl], *xs], gru._merged_zr(), out=z, epilogue=1, e0=cz, e1=cr, h=h, out2_c8=self.rh[lvl])
+            d1 = c8.desc([self.rh[lvl], *xs], gru.convq, out=h, out_c8=self.hc8[lvl], epilogue=2, e0=cq, e1=z, h=h)
+            if c8.launch_chain(d0, None, 4, d1, 4, self._chain_flags(("gru", lvl), d0, 4, 1), h, err=self.err,
+                               max_blocks=CHAIN_BLOCKS, timing_only=(CHAIN == 2)):
+                return
         z = c8.gate_zr([self.hc8[lvl], *xs], gru._merged_zr(), cz, cr, h, rh_c8=self.rh[lvl], cfg=cfg_zr)
         c8.gate_out([self.rh[lvl], *xs], gru.convq, cq, z, h, h, out_c8=self.hc8[lvl], cfg=cfg_q)
 
@@ -383,10 +410,15 @@ class C8Loop:
             c8.pack(cor, self.cor)
         join()
 
-    def _motion_tail(self, st):
+    def _motion_tail(self, st, chain=False):
         enc = self.ub.encoder
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convf2, relu=True, out_c8=self.cf, out_c8_ch0=64)
+        if chain and CHAIN and self.chain_ok and self.cfg["c2"] == 4 and self.cfg["enc"] == 3:
+            d2 = c8.desc([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["flow"])
+            if c8.launch_chain(d0, d1, 4, d2, 3, self._chain_flags("enc", d0, 4, 2), st["flow"], err=self.err,
+                               max_blocks=CHAIN_BLOCKS, timing_only=(CHAIN == 2)):
+                return
         c8.launch_pair(d0, d1, st["flow"], self.cfg["c2"])
         c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["flow"], cfg=self.cfg["enc"])
 
@@ -436,14 +468,14 @@ class C8Loop:
         hid = c8.conv2d_c8([self.hc8[0]], mh[0], relu=True, cfg=1)
         self.mask_out = _conv.conv2d(hid, _scaled_layer(mh[2], 0.25), out=self.mask_out)
 
-    def _mid(self, st):
+    def _mid(self, st, chain=False):
         n0, n1, n2 = st["net"]
         if PAIR_RESAMPLE:
             c8.resample_pair_c8(("pool", n0, self.pool0), ("interp", n2, self.up2))
         else:
             c8.pool2x_c8(n0, self.pool0)
             c8.interp_c8(n2, self.up2)
-        self._gru(1, self.grus[1], st, [self.pool0, self.up2], self.cfg["zr16"], self.cfg["q16"])
+        self._gru(1, self.grus[1], st, [self.pool0, self.up2], self.cfg["zr16"], self.cfg["q16"], chain=chain)
         if PAIR_RESAMPLE:
             c8.resample_pair_c8(("interp", n1, self.up1), ("pool", n1, self.pool1))
         else:
@@ -489,19 +521,19 @@ class C8Loop:
             else:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._mid(st)
+                self._mid(st, chain=True)
             if not HEAD_FIRST:
                 self._head(st, front)
             if not front:
                 self._motion_front(st)
-            self._motion_tail(st)
+            self._motion_tail(st, chain=True)
             main.wait_stream(side)
         else:
             self._head(st, front)
-            self._mid(st)
+            self._mid(st, chain=True)
             if not front:
                 self._motion_front(st)
-            self._motion_tail(st)
+            self._motion_tail(st, chain=True)
 
     def prologue(self, st):
         """Per pair: hidden states into their C8S twins, the coarsest and the middle GRU of iteration 0 and its motion features."""
@@ -555,10 +587,15 @@ class C8LoopIGEV(C8Loop):
             c8.pack(_conv.conv2d(geo, enc.convc1, relu=True), self.cor)
         join()
 
-    def _motion_tail(self, st):
+    def _motion_tail(self, st, chain=False):
         enc = self.ub.encoder
         d0 = c8.desc([self.cor], enc.convc2, relu=True, out_c8=self.cf, out_c8_ch0=0)
         d1 = c8.desc([self.flo], enc.convd2, relu=True, out_c8=self.cf, out_c8_ch0=64)
+        if chain and CHAIN and self.chain_ok and self.cfg["c2"] == 4 and self.cfg["enc"] == 3:
+            d2 = c8.desc([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["disp"])
+            if c8.launch_chain(d0, d1, 4, d2, 3, self._chain_flags("enc", d0, 4, 2), st["disp"], err=self.err,
+                               max_blocks=CHAIN_BLOCKS, timing_only=(CHAIN == 2)):
+                return
         c8.launch_pair(d0, d1, st["disp"], self.cfg["c2"])
         c8.conv2d_c8([self.cf], enc.conv, relu=True, out_c8=self.mf, tail=st["disp"], cfg=self.cfg["enc"])
 

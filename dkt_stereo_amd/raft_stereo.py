@@ -115,14 +115,30 @@ class _Shadow:
             if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str)):
                 setattr(self.model, k, v)
 
-    def _run(self, master, backend, args, kwargs):
+    def _run(self, master, backend, ready, autocast, args, kwargs):
         torch.cuda.set_device(self.device)
-        with _conv.use_backend(backend):
+        mine = torch.cuda.current_stream(self.device)
+        mine.wait_event(ready)                       # the inputs as the caller's stream left them
+        with _conv.use_backend(backend), torch.autocast("cuda", enabled=autocast[0], dtype=autocast[1]):
             self._sync(master)
-            return self.model(*args, **kwargs)
+            out = self.model(*args, **kwargs)
+        done = torch.cuda.Event()
+        done.record(mine)
+        return out, done
 
     def run(self, master, *args, **kwargs):
-        return self.pool.submit(self._run, master, _conv.get_backend(), args, kwargs).result()
+        """The forward on the worker thread.  The worker issues on the device's default stream: it waits for an event the
+        caller records on ITS current stream (parallel_apply's caller may be on another one), and the caller's stream waits
+        for the worker's work before it touches the results; the caller's autocast state is carried over.  Memory: one
+        extra copy of the weights plus the captured loop's buffers per device, also on the master's own device."""
+        with torch.cuda.device(self.device):
+            caller = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(caller)
+            autocast = (torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype())
+            out, done = self.pool.submit(self._run, master, _conv.get_backend(), ready, autocast, args, kwargs).result()
+            caller.wait_event(done)
+        return out
 
 
 _SHADOWS = weakref.WeakKeyDictionary()             # master module -> {device index: _Shadow}

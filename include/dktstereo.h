@@ -481,6 +481,20 @@ int dkt_head_finish(const float *planes, long planes_bstride, int n_co, const fl
                     long diff_out_bstride, int B, int nout, int H, int W, int device, void *stream);
 /* two independent convolutions in one launch (the coarsest GRU rides with the finest); cfg != 0 */
 int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_desc *d1, int cfg, int device, void *stream);
+/* Round 5: two DEPENDENT layers in one launch -- stage 0 = d0a [and d0b, an independent
+ * second problem of the same size: BasicMotionEncoder's convc2 | convf2, core/update.py:78-79,84-85], stage 1 = d1, which
+ * reads what stage 0 writes [encoder.conv, core/update.py:80,85; or ConvGRU's q convolution behind its z|r convolution,
+ * core/update.py:27-31].  A stage-1 tile waits for the flags of the stage-0 tiles under its patch instead of a kernel
+ * boundary (gru_c8.hip's protocol).  cfg0 / cfg1: tile shapes of the stages, (4, 3) or (4, 4).
+ *   flags       : dkt_conv2d_c8_chain_flag_words(d0a, cfg0, 1 or 2) zero-initialised words owned by this pair of layers;
+ *   err_word    : optional, set to 2 when a wait timed out (results invalid);
+ *   max_blocks  : bound on the launch's blocks (0 = what the device holds).  Every block of a chain launch must stay
+ *                 resident while it may wait: chains that can run AT THE SAME TIME on different streams must fit the device
+ *                 together (256 each for two chains on MI355X);
+ *   timing_only : 1 = no waits, no publishes -- the upper bound of what the fusion can buy; results are WRONG. */
+long dkt_conv2d_c8_chain_flag_words(const dkt_conv_c8_desc *d0, int cfg0, int nprob);
+int dkt_conv2d_c8_chain(const dkt_conv_c8_desc *d0a, const dkt_conv_c8_desc *d0b, int cfg0, const dkt_conv_c8_desc *d1, int cfg1,
+                        unsigned *flags, unsigned *err_word, int max_blocks, int timing_only, int device, void *stream);
 
 /* Round 4: one whole ConvGRU step (core/update.py:23-32 == meta_arch/igev_stereo/update.py:32-41) in ONE launch on C8S
  * operands (csrc/gru_c8.hip):

@@ -277,3 +277,75 @@ def test_precision_schedule_runs_and_default_is_untouched(golden):
     g = golden("raft_e2e")
     s = int(g["256x512_it32/stride"])
     assert maxabs(again[:, :, ::s, ::s], g["256x512_it32/flow_up"]) <= 1e-3
+
+
+# ---- chain launches (dkt_conv2d_c8_chain): two dependent layers, one launch, a flag round instead of the kernel boundary -----------
+@torch.no_grad()
+@pytest.mark.parametrize("B,H,W,blocks", [(1, 184, 312, 256), (2, 92, 156, 96), (1, 37, 45, 0), (3, 64, 128, 40)])
+def test_chain_motion_tail_equals_separate_launches(B, H, W, blocks):
+    """convc2 | convf2 -> encoder.conv (core/update.py:78-80,84-85) as one launch: the same bits as the pair launch + the single
+    launch, launch after launch on the same flag words (every block several tiles, waits across rounds)."""
+    from dkt_stereo_amd import conv_c8 as c8
+    torch.manual_seed(H + B)
+    c2, f2, cv = (torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV) for _ in range(2)) + (torch.nn.Conv2d(128, 126, 3, padding=1).to(DEV),)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    flags = None
+    for step in range(3):
+        cor, flo = (c8.pack(torch.randn(B, 64, H, W, device=DEV)) for _ in range(2))
+        flow = torch.randn(B, 2, H, W, device=DEV)
+        cf_a, cf_b = c8.ActC8(B, 128, H, W, DEV), c8.ActC8(B, 128, H, W, DEV)
+        mf_a, mf_b = c8.ActC8(B, 128, H, W, DEV, tail=2), c8.ActC8(B, 128, H, W, DEV, tail=2)
+        d0 = c8.desc([cor], c2, relu=True, out_c8=cf_a, out_c8_ch0=0)
+        d1 = c8.desc([flo], f2, relu=True, out_c8=cf_a, out_c8_ch0=64)
+        c8.launch_pair(d0, d1, flow, 4)
+        c8.conv2d_c8([cf_a], cv, relu=True, out_c8=mf_a, tail=flow, cfg=3)
+        e0 = c8.desc([cor], c2, relu=True, out_c8=cf_b, out_c8_ch0=0)
+        e1 = c8.desc([flo], f2, relu=True, out_c8=cf_b, out_c8_ch0=64)
+        e2 = c8.desc([cf_b], cv, relu=True, out_c8=mf_b, tail=flow)
+        if flags is None:
+            flags = c8.chain_flags(e0, 4, 2, DEV)
+        assert c8.launch_chain(e0, e1, 4, e2, 3, flags, flow, err=err, max_blocks=blocks)
+        assert torch.equal(cf_b.t, cf_a.t) and torch.equal(mf_b.t, mf_a.t), step
+    assert int(err.item()) == 0 and int(flags.min()) == 3 and int(flags.max()) == 3
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("B,H,W,blocks", [(1, 92, 156, 256), (2, 46, 78, 64), (4, 92, 156, 256)])
+def test_chain_gru_equals_two_launches(B, H, W, blocks):
+    """The middle ConvGRU (z|r + gates -> q + in-place state update, core/update.py:23-32) as one chain launch, three dependent
+    steps: bit for bit the two-launch form."""
+    from test_gpu_round4 import _State, _make
+    from dkt_stereo_amd import conv_c8 as c8
+    args = _make(B, H, W, [128, 128], seed=7 + B)
+    a, b = _State(*args), _State(*args)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    z = torch.empty_like(b.h)
+    flags = None
+    for step in range(3):
+        za = c8.gate_zr([a.hc8, *a.xs], a.gru._merged_zr(), a.cz, a.cr, a.h, rh_c8=a.rh, cfg=4)
+        c8.gate_out([a.rh, *a.xs], a.gru.convq, a.cq, za, a.h, a.h, out_c8=a.hc8, cfg=4)
+        d0 = c8.desc([b.hc8, *b.xs], b.gru._merged_zr(), out=z, epilogue=1, e0=b.cz, e1=b.cr, h=b.h, out2_c8=b.rh)
+        d1 = c8.desc([b.rh, *b.xs], b.gru.convq, out=b.h, out_c8=b.hc8, epilogue=2, e0=b.cq, e1=z, h=b.h)
+        if flags is None:
+            flags = c8.chain_flags(d0, 4, 1, DEV)
+        assert c8.launch_chain(d0, None, 4, d1, 4, flags, b.h, err=err, max_blocks=blocks)
+        assert torch.equal(b.h, a.h) and torch.equal(b.hc8.t, a.hc8.t) and torch.equal(b.rh.t, a.rh.t), step
+    assert int(err.item()) == 0
+
+
+@torch.no_grad()
+def test_loop_with_chain_launches_equals_default(monkeypatch):
+    """The whole forward with both chains on (7 dispatches per unit) against the default loop: the same bits."""
+    from dkt_stereo_amd import loop_c8
+    c = _cases.E2E_CASES["736x1248_it32"]
+    i1, i2 = (G(t) for t in _synth.image_pair(c["seed"], 1, c["H"], c["W"], c["shift"]))
+    m0, _ = _raft()
+    _, want = m0(i1, i2, iters=8, test_mode=True)
+    monkeypatch.setattr(loop_c8, "CHAIN", 1)
+    m1, _ = _raft()
+    _, got = m1(i1, i2, iters=8, test_mode=True)
+    _, again = m1(i1, i2, iters=8, test_mode=True)
+    lp = m1._graph_state["c8"]
+    assert lp.unit_launches.count("dkt_conv2d_c8_chain") == 2 and len(lp.unit_launches) == 7, lp.unit_launches
+    assert not lp.take_error()
+    assert torch.equal(got, want) and torch.equal(again, want)
