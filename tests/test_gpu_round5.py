@@ -287,7 +287,8 @@ def test_chain_motion_tail_equals_separate_launches(B, H, W, blocks):
     launch, launch after launch on the same flag words (every block several tiles, waits across rounds)."""
     from dkt_stereo_amd import conv_c8 as c8
     torch.manual_seed(H + B)
-    c2, f2, cv = (torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV) for _ in range(2)) + (torch.nn.Conv2d(128, 126, 3, padding=1).to(DEV),)
+    c2, f2 = (torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV) for _ in range(2))
+    cv = torch.nn.Conv2d(128, 126, 3, padding=1).to(DEV)
     err = torch.zeros(1, device=DEV, dtype=torch.int32)
     flags = None
     for step in range(3):
