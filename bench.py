@@ -521,10 +521,10 @@ def main():
         "vs_baseline": None,
         # the arithmetic type of the path, not a precision claim: tensors and accumulation are fp32, every product of the
         # convolutions is evaluated on the fp16 matrix pipe from split operands (see "precision")
-        "dtype": ("f32 io/accumulate; REDUCED-PRECISION SCHEDULE (not the headline): refinement iterations 1..%d with weights and activations "
-                  "rounded to fp16 (1 MFMA product), %d..%d with activations rounded to fp16 (2 products), %d..%d fp32-class (3 products); "
-                  "encoders, correlation volume, lookup, up-sampling fp32-class / exact fp32"
-                  % (schedule[0], schedule[0] + 1, schedule[0] + schedule[1], schedule[0] + schedule[1] + 1, args.iters))
+        "dtype": ("f32 io/accumulate; REDUCED-PRECISION SCHEDULE (not the headline): of the %d refinement iterations the first %d with weights "
+                  "and activations rounded to fp16 (1 MFMA product), the next %d with activations rounded to fp16 (2 products), the last "
+                  "%d fp32-class (3 products); encoders, correlation volume, lookup, up-sampling fp32-class / exact fp32"
+                  % (args.iters, schedule[0], schedule[1], args.iters - sum(schedule)))
                  if model.precision_schedule else
                  {"f16x3": "f32 io/accumulate; convolution products = 3x fp16-split MFMA (22-bit operands); lookup / correlation exact fp32",
                   "f16x2": "f32 io/accumulate; convolution products = 2x fp16-split MFMA (NOT a parity path)",

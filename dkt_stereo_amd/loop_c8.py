@@ -20,6 +20,33 @@ from .update import interp, pool2x, _leading_outputs, _scaled_layer
 
 #: tile shapes (conv_c8.hip c8_dispatch) per layer class
 _CFG = dict(zr08=1, q08=2, zr16=4, q16=4, head=2, enc=3, c2=4)
+def _env_cfg():
+    """DKT_C8_CFG="zr16=1,q16=2": tile shapes per layer class for A/B runs (conv_c8.hip c8_dispatch)."""
+    out = {}
+    for kv in os.environ.get("DKT_C8_CFG", "").split(","):
+        if "=" in kv:
+            k, v = kv.split("=")
+            out[k.strip()] = int(v)
+    return out
+
+
+def _cfg_for_batch(B, n1):
+    """Tile shapes that depend on how many tiles the batch gives (round 5).  _CFG's 4-row / 64-channel tiles for the middle GRU
+    and the 64-channel pair exist to put enough blocks on the device at ONE pair per launch; with several pairs per launch the
+    wide 8-row tiles (fewer fragment reads per MFMA) have enough tiles of their own."""
+    out = {}
+    tiles8 = B * ((n1.shape[2] + 7) // 8) * ((n1.shape[3] + 31) // 32)
+    if tiles8 >= _WIDE_MID_TILES:
+        out.update(_CFG_WIDE_MID)
+    out.update(_env_cfg())
+    return out
+
+
+#: 8 x 32 tiles of the middle level (x batch) from which its GRU takes the wide tiles of _CFG_WIDE_MID (measured at cfg4's 8 pairs
+#: per launch, profiles/r05_b8_variants.txt); DKT_C8_WIDE_MID_TILES overrides
+_WIDE_MID_TILES = int(os.environ.get("DKT_C8_WIDE_MID_TILES", "1000000"))
+_CFG_WIDE_MID = dict(zr16=1, q16=2)
+
 #: flow head with the hidden tensor reduced in conv1's epilogue (FUSE_HEAD = False: hidden tensor + few-output kernel)
 FUSE_HEAD = True
 
@@ -148,6 +175,7 @@ class C8Loop:
         # 256 x 512 / 32 iterations, 14.8 against 17.5 at 480 x 640; 544 x 960 -- 136 tiles -- and up: the one launch wins)
         tiles = B * ((n0.shape[2] + 7) // 8) * ((n0.shape[3] + 31) // 32)
         self.cfg = dict(_CFG)
+        self.cfg.update(_cfg_for_batch(B, n1))
         self.fuse_gru = FUSE_GRU and tiles >= FUSE_GRU_MIN_TILES
         if not self.fuse_gru and FUSE_GRU:
             self.cfg.update(zr08=_CFG_SMALL["zr08"], q08=_CFG_SMALL["q08"])

@@ -135,7 +135,7 @@ class _Shadow:
             caller = torch.cuda.current_stream(self.device)
             ready = torch.cuda.Event()
             ready.record(caller)
-            autocast = (torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype())
+            autocast = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
             out, done = self.pool.submit(self._run, master, _conv.get_backend(), ready, autocast, args, kwargs).result()
             caller.wait_event(done)
         return out
