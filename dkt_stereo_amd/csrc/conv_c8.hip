@@ -419,7 +419,7 @@ __device__ __forceinline__ void conv_c8_body(const C8ArgsPair &ap, const int nb0
         __builtin_amdgcn_s_barrier();                            // `red` is free again before the next tile's epilogue
     };
     auto epilogue = [&]() {
-        if constexpr (NW == 8 && NF <= 2) {      // (only the 128 co x 8 rows shape carries the head epilogue: in the NF = 4
+        if constexpr (NW == 8) {                 // (the two 8-wave shapes carry the head epilogue; round 4: in the NF = 4
             if (a.epi == 3) {                    //  shapes its code costs hundreds of spilled registers)
                 epilogue_head();
                 return;
@@ -953,7 +953,7 @@ static int c8_launch(C8Args a, int B, hipStream_t st, const C8Args *second, int 
     size_t lds = (size_t)2 * (NIA * NW > NPR ? NPR + 1 : NPR) * 1024 + (size_t)RING * WM * 4096;
     const bool head = a.epi == 3 || (second && second->epi == 3);
     if (head) {
-        if (NW != 8 || NF > 2) return DKT_E_UNSUPPORTED;      // one block per CU: the extra LDS costs no residency
+        if (NW != 8) return DKT_E_UNSUPPORTED;                // one block per CU: the extra LDS costs no residency
         lds += (size_t)NW * NF * 9 * 32 * 4;
     }
     auto kern = conv_c8_kernel<WM, WN, NF, RING, PASSES>;
@@ -962,7 +962,7 @@ static int c8_launch(C8Args a, int B, hipStream_t st, const C8Args *second, int 
     (void)hipGetDevice(&dev);
     if (!slots[dev & 63]) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(lds + (NW == 8 && NF <= 2 && !head ? (size_t)NW * NF * 9 * 32 * 4 : 0)));
+                                           (int)(lds + (NW == 8 && !head ? (size_t)NW * NF * 9 * 32 * 4 : 0)));
         if (e != hipSuccess) return (int)e;
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -1263,6 +1263,7 @@ extern "C" int dkt_head_finish(const float *planes, long planes_bstride, int n_c
 extern "C" int dkt_conv2d_c8_head_blocks(int Cout, int cfg) {
     const int n64 = (Cout + 63) / 64;
     if (cfg == 2) return (n64 + 1) / 2;
+    if (cfg == 1) return (n64 + 3) / 4;
     return DKT_E_UNSUPPORTED;
 }
 
