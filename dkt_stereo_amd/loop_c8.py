@@ -44,7 +44,7 @@ def _cfg_for_batch(B, n1):
 
 #: 8 x 32 tiles of the middle level (x batch) from which its GRU takes the wide tiles of _CFG_WIDE_MID (measured at cfg4's 8 pairs
 #: per launch, profiles/r05_b8_variants.txt); DKT_C8_WIDE_MID_TILES overrides
-_WIDE_MID_TILES = int(os.environ.get("DKT_C8_WIDE_MID_TILES", "1000000"))
+_WIDE_MID_TILES = int(os.environ.get("DKT_C8_WIDE_MID_TILES", "400"))
 _CFG_WIDE_MID = dict(zr16=1, q16=2)
 
 #: flow head with the hidden tensor reduced in conv1's epilogue (FUSE_HEAD = False: hidden tensor + few-output kernel)
