@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5 evidence on a GPU box -> gpurun_out/ (copy what is to be kept into profiles/):  bash tools/collect_profiles_r05.sh [steps...]
-# steps: tests prof bench b8 trace stress pmc sched   (default: tests prof bench b8 trace)
+# steps: tests prof bench b8 trace stress pmc sched schedline configs smoke   (default: tests prof bench b8 trace)
 R=r05
 O=gpurun_out
 STEPS=${@:-tests prof bench b8 trace}
@@ -21,5 +21,8 @@ trace) timeout 600 python tools/gru_c8_trace.py --batch=1 --batch=8 2>&1 | grep 
 stress) timeout 1500 python tools/stress_forward.py 1000 2>&1 | grep -v amdgpu > $O/${R}_stress_forward.txt ;;
 pmc) bash tools/pmc/run_pmc_r05.sh 1 > $O/${R}_pmc.log 2>&1; python tools/pmc/make_traffic_r05.py $O/r05_pmc 1 --profiles >> $O/${R}_pmc.log 2>&1 ;;
 sched) timeout 2400 python tools/precision_schedule.py 2>&1 | grep -v amdgpu > $O/${R}_precision_schedule.txt ;;
+schedline) timeout 600 python bench.py --steps 20 --warmup 3 --schedule 0,16 --skip-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_sched.json ;;
+configs) timeout 900 python tools/bench_configs.py 2>/dev/null | grep "^{" > $O/${R}_bench_configs.jsonl ;;
+smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu | tail -3 > $O/${R}_smoke.txt ;;
 esac; done
 ls -la $O | tail -20
