@@ -91,6 +91,17 @@ __device__ __forceinline__ float dkt_blend(float v0, float v1, const DktTap &t) 
     return __fmaf_rn(v1, t.w, __fmul_rn(v0, t.e));
 }
 
+// XCD-aware tile order of the persistent convolution kernels (round 5).  The dispatcher deals the blocks of a launch round-robin
+// to the part's 8 XCDs, each with an L2 of its own: with tile = block index, a tile's neighbours -- which read the same halo
+// rows of every operand -- sit on other XCDs, and every L2 fetches them again.  Of the n blocks that walk one problem, block lb
+// (problem-local index; blocks with equal lb & 7 share an XCD whatever the problem's first block is) takes the lb >> 3-th tile of
+// the contiguous run of tiles its XCD owns: neighbouring tiles share an L2.  A bijection of [0, n).  Fused ConvGRU launch:
+// 391.5 -> 380.1 us (B = 1), 3 125 -> 3 052 us (B = 8), profiles/r05_gru_c8_phases.txt.
+__device__ __forceinline__ int dkt_xcd_tile(int lb, int n) {
+    const int x = lb & 7, per = n >> 3, rem = n & 7;
+    return x * per + (x < rem ? x : rem) + (lb >> 3);
+}
+
 // ReLU that propagates NaN like torch.relu (fmaxf(NaN, 0) returns 0 and would turn a diverged
 // activation into a plausible-looking zero).
 __device__ __forceinline__ float dkt_relu(float v) {

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 1) void gru_c8_kernel(G8ArgsPair ap, int nb0) 
     const int iHW = a.H * a.W;
     const int nA = 8 + a.nxc, nB = a.nxc + 8;
 
-    int tile = (int)blockIdx.x - blk_first;
+    int tile = dkt_xcd_tile((int)blockIdx.x - blk_first, blk_count);      // (neighbouring tiles on one XCD: dkt_common.h)
     int b = tile / a.tiles_xy;
     int txy = tile - b * a.tiles_xy;
     int w0 = (txy % a.tiles_w) * 32, h0 = (txy / a.tiles_w) * TR;

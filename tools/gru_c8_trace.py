@@ -15,6 +15,9 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(HERE, "_build")
 
 
+TAG = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--tag=")] or [""])[0]
+
+
 def build(subs, trace=True):
     from dkt_stereo_amd import build as B
     os.makedirs(OUT, exist_ok=True)
@@ -39,12 +42,12 @@ def build(subs, trace=True):
         assert a in src, a
         src = src.replace(a, b)
     src = src.replace('#include "dkt_common.h"', '#include "%s/dkt_common.h"' % B.CSRC)
-    path = os.path.join(OUT, "gru_c8_trace.hip")
+    path = os.path.join(OUT, "gru_c8_trace%s.hip" % TAG)
     open(path, "w").write(src)
-    obj = os.path.join(OUT, "gru_c8_trace.o")
+    obj = os.path.join(OUT, "gru_c8_trace%s.o" % TAG)
     subprocess.check_call([B.HIPCC] + B.CFLAGS + B.EXTRA_FLAGS["gru_c8"] + ["-c", path, "-o", obj])
     objs = [os.path.join(B.OBJ_DIR, f) for f in sorted(os.listdir(B.OBJ_DIR)) if f.endswith(".o") and f != "gru_c8.o"]
-    lib = os.path.join(OUT, "libdktstereo_trace.so")
+    lib = os.path.join(OUT, "libdktstereo_trace%s.so" % TAG)
     subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", obj] + objs + ["-o", lib])
     return lib
 
@@ -96,7 +99,7 @@ if __name__ == "__main__":
     if "--build-only" in sys.argv:
         print(build(subs))
     else:
-        lib = os.path.join(OUT, "libdktstereo_trace.so")
+        lib = os.path.join(OUT, "libdktstereo_trace%s.so" % TAG)
         if not os.path.exists(lib) or "--rebuild" in sys.argv:
             lib = build(subs)
         bs = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--batch=")] or [1]
