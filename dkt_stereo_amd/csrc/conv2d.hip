@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : CONV_MIN_BLOCKS)) 
         tb = r / a.n_co;
     };
     int h0, w0, co_blk, b;            // tile being computed
-    int tile = dkt_xcd_tile((int)blockIdx.x - blk_first, blk_count);      // (neighbouring tiles on one XCD: dkt_common.h)
+    int tile = (int)blockIdx.x - blk_first;
     decode(tile, h0, w0, co_blk, b);
 
     // ---- staging.  Wave w stages channels 8w..8w+7 of every 32-channel chunk; its lanes walk

@@ -91,7 +91,7 @@ __device__ __forceinline__ float dkt_blend(float v0, float v1, const DktTap &t) 
     return __fmaf_rn(v1, t.w, __fmul_rn(v0, t.e));
 }
 
-// XCD-aware tile order of the persistent convolution kernels (round 5).  The dispatcher deals the blocks of a launch round-robin
+// XCD-aware tile order of the fused ConvGRU launch (round 5; in conv_c8.hip / conv2d.hip the same order measured 0.6 % slower).  The dispatcher deals the blocks of a launch round-robin
 // to the part's 8 XCDs, each with an L2 of its own: with tile = block index, a tile's neighbours -- which read the same halo
 // rows of every operand -- sit on other XCDs, and every L2 fetches them again.  Of the n blocks that walk one problem, block lb
 // (problem-local index; blocks with equal lb & 7 share an XCD whatever the problem's first block is) takes the lb >> 3-th tile of
