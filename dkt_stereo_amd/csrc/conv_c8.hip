@@ -961,8 +961,9 @@ static int c8_launch(C8Args a, int B, hipStream_t st, const C8Args *second, int 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!slots[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(lds + (NW == 8 && !head ? (size_t)NW * NF * 9 * 32 * 4 : 0)));
+        size_t want = lds + (NW == 8 && !head ? (size_t)NW * NF * 9 * 32 * 4 : 0);     // (room for a later head launch of this shape)
+        if (want > 160 * 1024) want = lds;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e != hipSuccess) return (int)e;
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, lds) != hipSuccess || per_cu < 1) per_cu = 1;
