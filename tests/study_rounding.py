@@ -4,7 +4,8 @@ fp16) grow LINEARLY with the number of reduced iterations, and would
 
 The oracle's update-block convolutions are re-run with their 3x3 inputs rounded to fp16 (a) to nearest -- what
 dkt_conv_c8_desc.passes = 2 computes -- and (b) stochastically (x + u * ulp, u ~ U(-1/2, 1/2), then to nearest: unbiased, and a
-different error in every iteration); final disparity against the exact forward, per number of iterations.
+different error in every iteration), and (c) as fp16 hi x hi plus the two cross terms on fp8 (e4m3) operands -- a form gfx950's
+f8f6f4 MFMAs would run in 2 product-equivalents; final disparity against the exact forward, per number of iterations.
     python tests/study_rounding.py [HxW] [iters]"""
 import os
 import sys
@@ -39,9 +40,28 @@ def rounded(x):
     return (x + u * ulp).half().float()
 
 
+def q8(t):
+    """fp8 (e4m3) rounding with a per-tensor power-of-two scale (the hardware's MX formats carry one per 32 elements: this is
+    the pessimistic end)."""
+    m = float(t.abs().max())
+    if m == 0.0:
+        return t
+    s = 2.0 ** torch.floor(torch.log2(torch.tensor(448.0 / m))).item()
+    return (t * s).to(torch.float8_e4m3fn).float() / s
+
+
 def conv(sd_, name, x, stride=1):
     w = sd_[name + ".weight"]
     if mode["m"] != "exact" and name.startswith("update_block.") and w.shape[2] == 3 and w.shape[1] >= 64:
+        if mode["m"] == "f8x":
+            # hi x hi on fp16, the two cross terms on fp8 operands (half the MFMA time each on gfx950): 2 product-equivalents
+            import torch.nn.functional as F
+            xh, wh = x.half().float(), w.half().float()
+            xl, wl = x - xh, w - wh
+            pad = (w.shape[2] // 2, w.shape[3] // 2)
+            y = F.conv2d(xh, wh, sd_[name + ".bias"], stride=stride, padding=pad)
+            y = y + F.conv2d(q8(xl), q8(wh), None, stride=stride, padding=pad) + F.conv2d(q8(xh), q8(wl), None, stride=stride, padding=pad)
+            return y
         x = rounded(x)
     return real_conv(sd_, name, x, stride)
 
@@ -49,11 +69,12 @@ def conv(sd_, name, x, stride=1):
 to._conv = conv
 with torch.no_grad():
     res = {}
-    for m in ("exact", "rn", "sr"):
+    for m in ("exact", "rn", "sr", "f8x"):
         mode["m"] = m
         res[m] = [to.raft_stereo_forward(sd, dict(BASE_CONFIG), i1, i2, k)[1] for k in (iters // 4, iters // 2, iters)]
 print("# %dx%d, final disparity: max-abs / mean-abs against the exact forward (oracle, CPU)" % (H, W))
-print("%-10s %28s %28s" % ("iterations", "fp16 to nearest (2 products)", "fp16 dithered"))
+print("%-10s %28s %28s %32s" % ("iterations", "fp16 to nearest (2 products)", "fp16 dithered", "fp16 hi*hi + fp8 cross terms"))
 for j, k in enumerate((iters // 4, iters // 2, iters)):
-    d1, d2 = (res["rn"][j] - res["exact"][j]).abs(), (res["sr"][j] - res["exact"][j]).abs()
-    print("%-10d %14.3e / %9.3e %16.3e / %9.3e" % (k, float(d1.max()), float(d1.mean()), float(d2.max()), float(d2.mean())))
+    d = [(res[m][j] - res["exact"][j]).abs() for m in ("rn", "sr", "f8x")]
+    print("%-10d %14.3e / %9.3e %16.3e / %9.3e %18.3e / %9.3e" % (k, float(d[0].max()), float(d[0].mean()), float(d[1].max()), float(d[1].mean()),
+                                                                float(d[2].max()), float(d[2].mean())))
