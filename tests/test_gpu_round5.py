@@ -350,3 +350,55 @@ def test_loop_with_chain_launches_equals_default(monkeypatch):
     assert lp.unit_launches.count("dkt_conv2d_c8_chain") == 2 and len(lp.unit_launches) == 7, lp.unit_launches
     assert not lp.take_error()
     assert torch.equal(got, want) and torch.equal(again, want)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("passes", [2, 1])
+def test_chain_launch_at_reduced_passes_equals_separate_launches(passes):
+    """The chain launch honours dkt_conv_c8_desc.passes like the single launches (the same step sequences, one kernel)."""
+    from dkt_stereo_amd import conv_c8 as c8
+    B, H, W = 1, 92, 156
+    torch.manual_seed(passes)
+    c2, f2 = (torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV) for _ in range(2))
+    cv = torch.nn.Conv2d(128, 126, 3, padding=1).to(DEV)
+    cor, flo = (c8.pack(torch.randn(B, 64, H, W, device=DEV)) for _ in range(2))
+    flow = torch.randn(B, 2, H, W, device=DEV)
+    cf_a, cf_b = c8.ActC8(B, 128, H, W, DEV), c8.ActC8(B, 128, H, W, DEV)
+    mf_a, mf_b = c8.ActC8(B, 128, H, W, DEV, tail=2), c8.ActC8(B, 128, H, W, DEV, tail=2)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    with c8.passes(passes):
+        c8.launch_pair(c8.desc([cor], c2, relu=True, out_c8=cf_a, out_c8_ch0=0), c8.desc([flo], f2, relu=True, out_c8=cf_a, out_c8_ch0=64), flow, 4)
+        c8.conv2d_c8([cf_a], cv, relu=True, out_c8=mf_a, tail=flow, cfg=3)
+        e0 = c8.desc([cor], c2, relu=True, out_c8=cf_b, out_c8_ch0=0)
+        e1 = c8.desc([flo], f2, relu=True, out_c8=cf_b, out_c8_ch0=64)
+        e2 = c8.desc([cf_b], cv, relu=True, out_c8=mf_b, tail=flow)
+        assert e0.passes == passes and e2.passes == passes
+        assert c8.launch_chain(e0, e1, 4, e2, 3, c8.chain_flags(e0, 4, 2, DEV), flow, err=err, max_blocks=128)
+    assert torch.equal(cf_b.t, cf_a.t) and torch.equal(mf_b.t, mf_a.t) and int(err.item()) == 0
+    # and it is the reduced arithmetic: the fp32-class launch differs
+    cf_c = c8.ActC8(B, 128, H, W, DEV)
+    c8.launch_pair(c8.desc([cor], c2, relu=True, out_c8=cf_c, out_c8_ch0=0), c8.desc([flo], f2, relu=True, out_c8=cf_c, out_c8_ch0=64), flow, 4)
+    assert not torch.equal(cf_c.t, cf_a.t)
+
+
+@torch.no_grad()
+def test_igev_loop_under_a_precision_schedule(monkeypatch):
+    """IGEV's loop (C8LoopIGEV) takes the module-level schedule: units of three kinds from their own graphs, a result near the
+    fp32-class one, reproducible; without the schedule the default result bit for bit."""
+    from test_gpu_round2 import _igev_setup
+    from dkt_stereo_amd import igev_loop, loop_c8
+    c = _cases.IGEV_LOOP_CASES["kitti"]
+    blk, geo_fn, d0, coords, net, inp, _ = _igev_setup(c)
+    run = lambda cache: igev_loop.igev_iterate(blk, geo_fn, d0, coords, [t.clone() for t in net], inp, 12, cache=cache)[0]
+    ref = run({})
+    monkeypatch.setattr(loop_c8, "SCHEDULE", (3, 4))
+    cache = {}
+    a = run(cache)
+    b = run(cache)
+    lp = cache["state"].c8
+    assert torch.equal(a, b) and {k[0] for k in lp.graph} == {1, 2, 3}
+    d = maxabs(a, ref)
+    print("IGEV schedule (3, 4) vs fp32-class: %.3e" % d)
+    assert 0 < d <= 5e-2
+    monkeypatch.setattr(loop_c8, "SCHEDULE", None)
+    assert torch.equal(run({}), ref)
