@@ -87,6 +87,14 @@ def run(lib, pair=True, reps=300, B=1):
         for k, n in enumerate(names):
             d = t[:, k + 1] - t[:, k]
             print("  %-18s median %.1f  min %.1f  max %.1f us" % (n, float(d.median()), float(d.min()), float(d.max())))
+        if r == 0 and "--by-xcd" in sys.argv:
+            # which blocks are the slow ones: phase A per XCD (block index & 7) and for the riders' neighbours
+            ta = t_all[0, :nb0]
+            for x in range(8):
+                d = (ta[x::8, 2] - ta[x::8, 1])
+                d = d[d > 0]
+                print("    XCD %d: %3d blocks, phase A median %.1f  max %.1f; done median %.1f" %
+                      (x, d.numel(), float(d.median()), float(d.max()), float((ta[x::8, 5] - t0)[ta[x::8, 5] > 0].median())))
         if r == 0:
             for k, n in ((2, "end of phase A"), (3, "published"), (4, "end of phase B"), (5, "done")):
                 d = t[:, k] - t0
