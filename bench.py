@@ -67,6 +67,13 @@ def parse():
     p.add_argument("--schedule", default=None, metavar="K1,K2",
                    help="precision schedule of the refinement loop (loop_c8.SCHEDULE): the first K1 iterations at one fp16 MFMA product "
                         "per block, the next K2 at two, the rest fp32-class.  A SEPARATE line, never the headline: `dtype` says what ran")
+    p.add_argument("--distinct-pairs", type=int, default=8, metavar="N",
+                   help="after the timed region: N DIFFERENT seeded pairs (shifts 12 / 40, amplitudes x0.5 ... x2) through the same model in "
+                        "the product's default mode (check_finite = True), each step timed on its own; reports recalibrations and the "
+                        "worst step (0 = skip)")
+    p.add_argument("--mixed-precision", action="store_true",
+                   help="args.mixed_precision = True (raft_stereo.py:95,156; the DKT teachers' default, tools/ft_dkt.py:317): encoders and "
+                        "refinement loop at one fp16 MFMA product per block.  A SEPARATE line, never the headline")
     p.add_argument("--conv-backend", default=None, choices=["f16x3", "f16x2", "f16", "miopen"],
                    help="update-block convolution path (default: the package default, f16x3)")
     a = p.parse_args()
@@ -197,8 +204,11 @@ def main():
     conv_backend_name = {"f16x3": "hip split-fp16 MFMA x3 (fp32-class, dkt_conv2d_f16s)",
                          "f16x2": "hip split-fp16 MFMA x2", "f16": "hip fp16 MFMA",
                          "miopen": "miopen-fp32"}[_conv.get_backend()]
-    model = RAFTStereo()
+    from dkt_stereo_amd.raft_stereo import make_args
+    model = RAFTStereo(make_args(mixed_precision=True)) if args.mixed_precision else RAFTStereo()
     schedule = None
+    if args.mixed_precision and not args.schedule:
+        args.schedule = "%d,0" % args.iters          # (what mixed_precision runs: reported in `dtype` like any schedule)
     if args.schedule:
         k = [int(x) for x in args.schedule.split(",")]
         schedule = (k[0], k[1] if len(k) > 1 else 0)
@@ -254,25 +264,78 @@ def main():
         t1 = time.perf_counter()
         model.check_finite = True
         gathered_batch = int(last.shape[0]) if last is not None else None      # (rank 0 holds all ranks' maps)
-        if last is not None and not bool(torch.isfinite(last).all()):
+        # the timed region ran without the per-forward check (no host synchronisation inside it): its post-conditions are read
+        # ONCE behind it -- the error word of the fused ConvGRU / chain launches (a time-out inside the region must not be
+        # reported as a valid run), finiteness, the C8S scale window
+        lp_t = (model._graph_state or {}).get("c8")
+        error_word, ranges_ok = 0, True
+        if lp_t is not None:
+            s_t = lp_t.status(last if world == 1 else None)
+            error_word, ranges_ok, finite_t = s_t.err, s_t.ranges_ok, s_t.finite
+        else:
+            finite_t = True
+        if last is not None and not (finite_t and bool(torch.isfinite(last).all())):
             raise SystemExit("bench.py: non-finite disparities in the timed region")
+        if error_word:
+            raise SystemExit("bench.py: a flag-synchronised launch timed out inside the timed region (error word %d): the run is invalid"
+                             % error_word)
+        if not ranges_ok:
+            raise SystemExit("bench.py: activations left the C8S scale window inside the timed region: the run is invalid")
 
         mine = t1 - t0
+        # the same steps once more in the product's DEFAULT mode (check_finite = True: one status launch + one host
+        # synchronisation per forward, repeats on a time-out / a left scale window): `value_default_mode`
+        sync()
+        td0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        mine_default = time.perf_counter() - td0
         # (gloo carries host tensors; RCCL device tensors)
-        elapsed = torch.tensor([mine], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        elapsed = torch.tensor([mine, mine_default], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         per_rank = [mine]
         if world > 1:
             every = [torch.zeros_like(elapsed) for _ in range(world)]
             dist.all_gather(every, elapsed)
-            per_rank = [float(t.item()) for t in every]
+            per_rank = [float(t[0].item()) for t in every]
             dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        elapsed = float(elapsed.item())
+        elapsed, elapsed_default = float(elapsed[0].item()), float(elapsed[1].item())
         ranks_seen = dist.get_world_size() if world > 1 else 1
         backend = dist.get_backend() if world > 1 else "none (single process)"
         if rank != 0:
             # the instrumented passes below are rank 0's (no collective inside them)
             dist.destroy_process_group()
             return
+
+        # N different pairs through the same model in default mode: a recalibration (new C8S scales +
+        # re-capture + the pair again) can only happen when the input changes, which 20 steps on one pair never show
+        distinct = None
+        if args.distinct_pairs > 0 and world == 1:
+            lp_d = (model._graph_state or {}).get("c8")
+            before = (lp_d.recalibrations, lp_d.calibrations) if lp_d is not None else (0, 0)
+            n_d = args.distinct_pairs
+            times, amps = [], []
+            for k in range(n_d):
+                amp = 0.5 * 4.0 ** (k / max(n_d - 1, 1))              # x0.5 ... x2, geometric
+                p1, p2 = _synth.image_pair(2000 + k, B, args.height, args.width, 12 if k % 2 == 0 else 40)
+                a1, a2 = torch.from_numpy(p1).to(dev) * amp, torch.from_numpy(p2).to(dev) * amp
+                torch.cuda.synchronize()
+                tk = time.perf_counter()
+                _, up_k = model(a1, a2, iters=args.iters, test_mode=True)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - tk)
+                amps.append(amp)
+            lp_d = (model._graph_state or {}).get("c8")
+            after = (lp_d.recalibrations, lp_d.calibrations) if lp_d is not None else (0, 0)
+            ts = sorted(times)
+            distinct = {"pairs": n_d, "amplitudes": [round(a, 3) for a in amps], "shifts": "12 / 40 alternating",
+                        "value": B * n_d / sum(times), "unit": "pairs/s", "median_step_ms": 1e3 * ts[len(ts) // 2],
+                        "worst_step_ms": 1e3 * ts[-1], "step_ms": [round(1e3 * t, 2) for t in times],
+                        "recalibrations": after[0] - before[0],
+                        "note": "default mode (check_finite = True), every step synchronised and timed on its own; a recalibration = "
+                                "new C8S scales from the maxima the pair left behind + re-capture of the loop's units + the pair again"}
+            model(i1, i2, iters=args.iters, test_mode=True)           # (back on the benchmark pair for the instrumented passes)
+            torch.cuda.synchronize()
 
         # Per-kernel timing.  The timed steps above replay the GRU iteration from a captured
         # HIP graph, where a single kernel cannot be bracketed by events; the same workload is
@@ -514,6 +577,13 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        # the timed region runs with check_finite = False (no host synchronisation inside it; its post-conditions -- error word,
+        # finiteness, scale window -- are read once behind it: `error_word`); the same steps in the product's default mode:
+        "value_default_mode": world * B * args.steps / elapsed_default,
+        "ms_per_step_default_mode": 1e3 * elapsed_default / args.steps,
+        "error_word": error_word,
+        "recalibrations": (distinct or {}).get("recalibrations"),
+        "distinct_pairs": distinct,
         "ms_per_iter": hot_ms / args.iters,
         "hot_path_ms_per_pair": hot_ms / B,
         "higher_is_better": True,
@@ -523,8 +593,11 @@ def main():
         # convolutions is evaluated on the fp16 matrix pipe from split operands (see "precision")
         "dtype": ("f32 io/accumulate; REDUCED-PRECISION SCHEDULE (not the headline): of the %d refinement iterations the first %d with weights "
                   "and activations rounded to fp16 (1 MFMA product), the next %d with activations rounded to fp16 (2 products), the last "
-                  "%d fp32-class (3 products); encoders, correlation volume, lookup, up-sampling fp32-class / exact fp32"
-                  % (args.iters, schedule[0], schedule[1], args.iters - sum(schedule)))
+                  "%d fp32-class (3 products); %s"
+                  % (args.iters, schedule[0], schedule[1], args.iters - sum(schedule),
+                     "args.mixed_precision = True (raft_stereo.py:95,156): the encoders' convolutions at one fp16 product as well; correlation "
+                     "volume, lookup, up-sampling exact fp32" if args.mixed_precision else
+                     "encoders, correlation volume, lookup, up-sampling fp32-class / exact fp32"))
                  if model.precision_schedule else
                  {"f16x3": "f32 io/accumulate; convolution products = 3x fp16-split MFMA (22-bit operands); lookup / correlation exact fp32",
                   "f16x2": "f32 io/accumulate; convolution products = 2x fp16-split MFMA (NOT a parity path)",

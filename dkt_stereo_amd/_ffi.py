@@ -93,8 +93,18 @@ class ResampleC8Job(ctypes.Structure):
                 ("Wo", ctypes.c_int), ("ch0", ctypes.c_int), ("kind", ctypes.c_int), ("scale", ctypes.c_float)]
 
 
+class C8RangeJob(ctypes.Structure):
+    """dkt_c8_range_job of include/dktstereo.h."""
+    _fields_ = [("t", ctypes.c_void_p), ("bstride_bytes", ctypes.c_long), ("B", ctypes.c_int), ("C", ctypes.c_int),
+                ("H", ctypes.c_int), ("W", ctypes.c_int), ("tail", ctypes.c_int)]
+
+
+#: DKT_STATUS_MAX_JOBS of include/dktstereo.h
+STATUS_MAX_JOBS = 8
+
 # name -> argtypes, mirrors include/dktstereo.h one to one
 SIGNATURES = {
+    "dkt_loop_status": [ctypes.POINTER(C8RangeJob), _i, _vp, _l, _vp, _vp, _i, _vp],
     "dkt_motion_front_c8": [ctypes.POINTER(MotionFrontDesc), _i, _vp],
     "dkt_resample_pair_c8": [ctypes.POINTER(ResampleC8Job), ctypes.POINTER(ResampleC8Job), _i, _vp],
     "dkt_gru_c8_flag_words": [_i, _i, _i],

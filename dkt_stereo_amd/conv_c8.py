@@ -314,6 +314,8 @@ def gru_desc(gru, h_c8, xs, rh_c8, cz, cr, cq, h, flags):
     d.B, d.H, d.W, d.hidden = h_c8.B, h_c8.H, h_c8.W, 128
     d.flags = flags.data_ptr()
     d.passes = current_passes()
+    if d.passes == 1 and sum((s.C + 15) // 16 for s in xs) % 2:
+        d.passes = 2                         # (the one-product kernel walks the x chunks in pairs, as conv_c8.desc)
     d._keep = (h_c8, xs, rh_c8, pk, cz, cr, cq, h, flags)
     return d
 
@@ -324,6 +326,8 @@ def gru_launch(d0, d1=None, err=None, ref=None):
     ref = d0._keep[7] if ref is None else ref
     L = _ffi.lib()
     e = None if err is None else err.data_ptr()
+    if d1 is not None:
+        d0.passes = d1.passes = max(d0.passes, d1.passes)          # (one instantiation runs both problems)
     if d1 is None:
         rc = L.dkt_gru_c8(ctypes.byref(d0), e, _ffi.device_of(ref), _ffi.stream_of(ref))
     else:

@@ -193,7 +193,7 @@ __device__ __forceinline__ void conv_c8_body(const C8ArgsPair &ap, const int nb0
                 const bool ok = lane >= n || (int)(v - sy.target) >= 0;
                 if (__all(ok)) break;
                 if (spins > (1u << 21)) {
-                    if (lane == 0 && sy.err) __hip_atomic_store((c8_gu32 *)sy.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0 && sy.err) __hip_atomic_fetch_or((c8_gu32 *)sy.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bit 1: a chain launch
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(512, 1) void gru_c8_kernel(G8ArgsPair ap, int nb0) 
                 const bool ok = !valid || (int)(v - target) >= 0;
                 if (__all(ok)) break;
                 if (spins > G8_SPIN_LIMIT) {
-                    if (lane == 0 && ap.err) __hip_atomic_store((g8_gu32 *)ap.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0 && ap.err) __hip_atomic_fetch_or((g8_gu32 *)ap.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bit 0: this launch
                     break;
                 }
                 __builtin_amdgcn_s_sleep(16);

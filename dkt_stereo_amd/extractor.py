@@ -461,10 +461,11 @@ class _Trunk(nn.Module):
             res, res_p = y, None
         return res
 
-    def _trunk(self, x):
+    def _trunk_begin(self, x):
+        """conv1 / norm1 / relu + layer1 (core/extractor.py:167-173): the full-resolution stage."""
         kind = self._layer1_c8_kind(x)
         if kind is not None:
-            return self.layer3(self.layer2(self._layer1_c8(x, kind)))
+            return self._layer1_c8(x, kind)
         if (FUSE_ENCODER and _plain_instance_norm(self.norm1) and _hip_ok(x)
                 and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             # fnet: the stem's normalise + ReLU pass is folded into its two consumers (layer1.0.conv1's staging, the
@@ -472,7 +473,12 @@ class _Trunk(nn.Module):
             x = LazyNorm(self.norm1, self.conv1(x), relu=True)
         else:
             x = conv_norm_act(self.conv1, self.norm1, x, True)
-        return self.layer3(self.layer2(self.layer1(x)))
+        return self.layer1(x)
+
+    def _trunk(self, x, begun=None):
+        """`begun`: the result of _trunk_begin(x) when the caller has enqueued that stage already (RAFTStereo._encode puts the
+        context encoder's full-resolution stage on the device BEFORE it enqueues the feature encoder on the second stream)."""
+        return self.layer3(self.layer2(self._trunk_begin(x) if begun is None else begun))
 
 
 class BasicEncoder(_Trunk):
@@ -550,10 +556,11 @@ class MultiBasicEncoder(_Trunk):
             t.record_stream(main)
         return scales
 
-    def forward(self, x, dual_inp=False, num_layers=3, head_post=None):
+    def forward(self, x, dual_inp=False, num_layers=3, head_post=None, begun=None):
         """head_post(i, [hidden_i, context_i]) -> anything: an optional per-scale epilogue of the caller (RAFT-Stereo's tanh /
-        relu / context_zqr convolution, raft_stereo.py:103-106) that then runs on the stream of that scale's heads."""
-        x = self._trunk(x)
+        relu / context_zqr convolution, raft_stereo.py:103-106) that then runs on the stream of that scale's heads.
+        begun: _trunk_begin(x) of this very input, already enqueued by the caller."""
+        x = self._trunk(x, begun)
         v = None
         if dual_inp:
             v = x

@@ -14,6 +14,7 @@ plain loop.  The feature / 3-D aggregation networks that produce the inputs are 
 library.
 """
 import os
+import threading
 import warnings
 import weakref
 
@@ -203,13 +204,102 @@ def _fingerprint(update_block):
     return tuple(fp)
 
 
+#: a replica made by nn.DataParallel hands its loop to a persistent per-device copy of the master's update block
+#: (_ShadowBlock): captured units and packed weights survive between forwards.  False: replicas run the plain loop
+REPLICA_SHADOWS = True
+
+
+class _ShadowBlock:
+    """IGEV twin of raft_stereo._Shadow (round 6).  nn.DataParallel (tools/ft_dkt.py:119-125: the
+    teachers run test_mode forwards under it, :193,199) hands every forward NEW replica modules on NEW threads, while the
+    captured loop, the packed weight images and the side streams of this library are keyed by module, weight storage and
+    thread.  A replica's igev_iterate is therefore run on ONE persistent copy of the master's update block per device, its
+    weights refreshed in place when the master's have changed, driven by ONE worker thread that lives as long as the master:
+    the C8S loop is captured once and replayed by every later forward, bit-identical to the master's own call."""
+
+    def __init__(self, device):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device = torch.device(device)
+        self.block = None
+        self.fingerprint = None
+        self.cache = {}
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dkt-igev-replica-cuda%d" % self.device.index)
+
+    @staticmethod
+    def _tensors(m):
+        return list(m.parameters()) + list(m.buffers())
+
+    def _sync(self, master):
+        src = self._tensors(master)
+        fp = tuple((t.data_ptr(), t._version) for t in src)
+        if self.block is None:
+            grus = [m for m in (getattr(master, n, None) for n in ("gru16", "gru08", "gru04")) if m is not None]
+            hidden = [int(g.convz.weight.shape[0]) for g in grus]
+            self.block = type(master)(master.args, hidden_dims=hidden).to(self.device)
+        if fp != self.fingerprint:
+            with torch.no_grad():
+                for d, t in zip(self._tensors(self.block), src):
+                    d.copy_(t)
+            self.fingerprint = fp
+        for a, b in zip(master.modules(), self.block.modules()):
+            b.training = a.training
+        for k, v in master.__dict__.items():                         # switches set on the instance (side_stream, ...)
+            if not k.startswith("_") and k not in ("training", "args") and isinstance(v, (bool, int, float, str, tuple, type(None))):
+                setattr(self.block, k, v)
+
+    def _run(self, master, backend, ready, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph):
+        torch.cuda.set_device(self.device)
+        mine = torch.cuda.current_stream(self.device)
+        mine.wait_event(ready)                       # the operands as the caller's stream left them
+        with _conv.use_backend(backend), torch.no_grad(), GPU_GUARD.shared():
+            self._sync(master)
+            out = _igev_iterate(self.block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph, self.cache)
+        done = torch.cuda.Event()
+        done.record(mine)
+        return out, done
+
+    def run(self, master, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph):
+        with torch.cuda.device(self.device):
+            caller = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(caller)
+            out, done = self.pool.submit(self._run, master, _conv.get_backend(), ready, geo_fn, init_disp, coords, net_list, inp_list,
+                                         iters, use_hip_graph).result()
+            caller.wait_event(done)
+            disp, mask, nets = out
+            for t in [disp, mask] + list(nets):      # allocated on the worker's stream, consumed on the caller's
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(caller)
+        return out
+
+
+_SHADOWS = weakref.WeakKeyDictionary()             # master update block -> {device index: _ShadowBlock}
+_SHADOW_LOCK = threading.Lock()
+
+
+def _shadow_of(master, device):
+    with _SHADOW_LOCK:
+        per = _SHADOWS.setdefault(master, {})
+        sh = per.get(device.index)
+        if sh is None:
+            sh = per[device.index] = _ShadowBlock(device)
+        return sh
+
+
 @torch.no_grad()
 def igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph=True, cache=None):
     """Returns (disp, mask_feat_4, net_list) after `iters` refinement iterations.
     `cache` (a dict the caller keeps, e.g. on its model) lets consecutive calls with the same shapes and
     weights reuse the captured graph (a new geometry volume of the same shapes is copied into the cached
     one's buffers; to avoid that copy keep ONE volume and call its ``rebuild``); without `cache` every call
-    captures anew.  ``slow_fast_gru`` runs the plain loop (igev_stereo.py:204-207)."""
+    captures anew.  ``slow_fast_gru`` runs the plain loop (igev_stereo.py:204-207).  An nn.DataParallel replica of an update
+    block runs on the master's persistent per-device copy (_ShadowBlock), whatever `cache` it brings."""
+    if (REPLICA_SHADOWS and use_hip_graph and getattr(update_block, "_is_replica", False) and init_disp.is_cuda
+            and not _conv.calibrating()):
+        master = getattr(update_block, "_dp_master", lambda: None)()
+        if master is not None:
+            return _shadow_of(master, init_disp.device).run(master, geo_fn, init_disp, coords, net_list, inp_list, iters,
+                                                            use_hip_graph)
     with GPU_GUARD.shared():
         return _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph, cache)
 
@@ -257,12 +347,17 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
     ub = update_block
     if USE_C8 and loop_c8.eligible_igev(ub, st.net[0].shape):
         out = _iterate_c8(ub, st, iters)
-        if st.c8.take_error():
-            # a fused ConvGRU launch gave up waiting for a neighbour tile (csrc/gru_c8.hip): the result is wrong.
-            # Two-launch form from here on, and this call is computed again from the caller's (untouched) inputs.
-            warnings.warn("dkt_stereo_amd: the fused ConvGRU launch timed out waiting for a neighbour tile; "
-                          "falling back to the two-launch form for this update block (one fused-GRU model per device)")
-            st.c8.disable_fused_gru()
+        word = st.c8.take_error_word()
+        if word:
+            # a fused ConvGRU (bit 0) or chain (bit 1) launch gave up waiting for a neighbour tile (csrc/gru_c8.hip; ADVICE
+            # r04): the result is wrong.  That form is left for good, and this call is computed again from the caller's
+            # (untouched) inputs.
+            if getattr(st.c8, "timed_out", 0) & word:
+                raise _conv._ffi.DktError("the IGEV loop reported a flag time-out in a form that had already been switched off")
+            st.c8.timed_out = getattr(st.c8, "timed_out", 0) | word
+            warnings.warn("dkt_stereo_amd: a %s launch timed out waiting for a neighbour tile; falling back to separate "
+                          "launches for this update block (one fused-GRU model per device)" % ("fused ConvGRU" if word & 1 else "chain"))
+            st.c8.on_error_word(word)
             return _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph,
                                  cache if cache is not None else dict(state=st))
         return out

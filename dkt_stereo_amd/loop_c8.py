@@ -147,6 +147,14 @@ def _eligible_block(ub, shape, enc_out, min_pixels=None):
             and enc.convc2.weight.shape[:2] == (64, 64))
 
 
+class LoopStatus:
+    """What C8Loop.status read back: the error word, finiteness of the result, the scale window, the maxima behind it."""
+    __slots__ = ("err", "finite", "ranges_ok", "maxima")
+
+    def __init__(self, err, finite, ranges_ok, maxima):
+        self.err, self.finite, self.ranges_ok, self.maxima = err, finite, ranges_ok, maxima
+
+
 class C8Loop:
     """Buffers and the captured unit for one (shape, weights) state of RAFTStereo._iterate_graphed."""
 
@@ -187,6 +195,9 @@ class C8Loop:
         self.unit_launches = None
         self.chain_flags, self.chain_z = {}, {}          # dkt_conv2d_c8_chain: flag words per layer pair, z of the middle GRU
         self.chain_ok = True
+        if CHAIN == 2:
+            import warnings
+            warnings.warn("DKT_C8_CHAIN=2: chain launches run WITHOUT their waits (a timing experiment): results are wrong")
         self.front = bool(FRONT) and self._front_supported(st)
         mask = getattr(ub, "mask", None)               # (IGEV's mask features are computed by its caller)
         self.mask_head = mask if (mask is not None and len(mask) == 3 and isinstance(mask[0], torch.nn.Conv2d)
@@ -196,6 +207,8 @@ class C8Loop:
         self.cx = None
         self.calibrated = not AUTOSCALE
         self.schedule = SCHEDULE         # (k1, k2) or None, see SCHEDULE
+        self.calibrations = 0            # trial runs (calibrate) and rescales without a trial (rescale_from) so far
+        self.recalibrations = 0          # of those: forced by a checked forward whose maxima had left the window
 
     def plan(self, iters):
         """MFMA passes of each of the `iters` units."""
@@ -323,6 +336,7 @@ class C8Loop:
             if not overflow:
                 break
         self.calibrated = True
+        self.calibrations += 1
         self.graph = self.graph_n = self.graph_last = None     # (a captured unit bakes the scales in)
         self.pinned = []
         self.par = 0
@@ -330,20 +344,93 @@ class C8Loop:
     def take_error(self):
         """True when a fused ConvGRU launch of this loop gave up waiting for a neighbour tile's flag (csrc/gru_c8.hip: the
         block then continued on stale r*h, so the results since are wrong).  One host synchronisation; the word is cleared, so a
-        later forward is not blamed for this one."""
-        bad = bool(int(self.err.item()))
-        if bad:
+        later forward is not blamed for this one.  (The checked forwards use `status`, which reads the same word.)"""
+        return bool(self.take_error_word())
+
+    def take_error_word(self):
+        """The error word itself (and clears it): bit 0 = a fused ConvGRU launch timed out, bit 1 = a chain launch did."""
+        word = int(self.err.item())
+        if word:
             self.err.zero_()
-        return bad
+        return word
+
+    def _range_acts(self):
+        """The C8S tensors whose magnitude follows the input (the state-like ones are bounded by 1)."""
+        return [self.cor, self.flo, self.cf, self.mf]
+
+    def status(self, result=None):
+        """Everything a checked forward wants to know about the pair it has just computed, for ONE host synchronisation
+        (dkt_loop_status: one launch over the four input-following C8S tensors and `result`, one 40-byte copy) -- round 5 paid
+        three synchronisations and ten torch reductions for the same facts.  Returns LoopStatus(err, finite, ranges_ok, maxima):
+        err = the error word (cleared), finite = `result` holds no Inf / NaN, maxima = (body, tail) per tensor of _range_acts in
+        scaled units (Inf / NaN where a scale overflowed fp16), ranges_ok = every non-zero maximum in [2^RANGE_LO, 2^RANGE_HI)."""
+        import numpy as np
+        acts = self._range_acts()
+        n = len(acts)
+        jobs = (_ffi.C8RangeJob * n)()
+        for j, a in enumerate(acts):
+            jobs[j].t, jobs[j].bstride_bytes = a.data_ptr(), a.bstride_bytes
+            jobs[j].B, jobs[j].C, jobs[j].H, jobs[j].W, jobs[j].tail = a.B, a.C, a.H, a.W, a.tail
+        dev = self.err.device
+        buf = getattr(self, "_status_buf", None)
+        if buf is None or buf.numel() != 2 + 2 * n:
+            buf = self._status_buf = torch.zeros(2 + 2 * n, device=dev, dtype=torch.int32)
+        src, count = None, 0
+        if result is not None:
+            t = result
+            if not t.is_contiguous():                      # (flow_up is the x plane of the up-sampled flow: check the whole tensor)
+                t = t._base if (t._base is not None and t._base.is_contiguous()) else t.contiguous()
+            if t.dtype != torch.float32:
+                t = t.float()
+            src, count = t.data_ptr(), t.numel()
+        rc = _ffi.lib().dkt_loop_status(jobs, n, src, count, self.err.data_ptr(), buf.data_ptr(), _ffi.device_of(self.err),
+                                        _ffi.stream_of(self.err))
+        _ffi.check(rc, "dkt_loop_status")
+        words = buf.cpu().numpy()                          # the forward's one host synchronisation
+        maxima = words[2:].astype(np.uint16).view(np.float16).astype(np.float32)
+        ok = True
+        if AUTOSCALE:
+            for v in maxima.tolist():
+                if v != 0.0 and not (2.0 ** RANGE_LO <= v < 2.0 ** RANGE_HI):
+                    ok = False
+        return LoopStatus(int(words[0]), not bool(words[1]), ok, maxima.reshape(n, 2))
+
+    def rescale_from(self, maxima):
+        """New scales for the input-following tensors from the maxima a finished pair left behind (status().maxima, scaled
+        units, all finite): what a recalibration needs when nothing overflowed -- no trial run (round 5 repeated the whole
+        loop eagerly, up to four times, before the pair could be computed again).  Captured units bake scales in: dropped."""
+        for a, (body, tail) in zip(self._range_acts(), maxima.tolist()):
+            if body > 0.0 and math.isfinite(body):
+                a.scale = a.scale * 2.0 ** (SCALE_EXP - math.floor(math.log2(body)))
+            if a.tail:
+                if tail > 0.0 and math.isfinite(tail):
+                    a.tail_scale = a.tail_scale * 2.0 ** (SCALE_EXP - math.floor(math.log2(tail)))
+            else:
+                a.tail_scale = a.scale
+        self.graph = self.graph_n = self.graph_last = None
+        self.pinned = []
+        self.par = 0
 
     def disable_fused_gru(self):
         """The two-launch form of the finest ConvGRU from here on (after a flag time-out: this device does not keep the
         launch's blocks resident, e.g. another process holds part of the CUs); captured units are dropped."""
         self.fuse_gru = False
-        self.chain_ok = False            # (the chain launches wait on flags the same way)
+        self.disable_chains()            # (the chain launches wait on flags the same way)
+
+    def disable_chains(self):
+        """No chain launches from here on (a chain's own time-out -- bit 1 of the error word -- leaves the fused ConvGRU
+        launch alone: ADVICE r05); captured units are dropped."""
+        self.chain_ok = False
         self.graph = self.graph_n = self.graph_last = None
         self.pinned = []
         self.par = 0
+
+    def on_error_word(self, word):
+        """Falls back from whichever flag-synchronised form raised `word` (take_error_word / status().err)."""
+        if word & 1:
+            self.disable_fused_gru()
+        elif word & 2:
+            self.disable_chains()
 
     def ranges_ok(self):
         """False when a tensor's maximum has left [2^RANGE_LO, 2^RANGE_HI) under its scale (another kind of input than the one

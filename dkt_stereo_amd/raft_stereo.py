@@ -15,6 +15,7 @@ is the training forward (tools/ft_dkt.py:223): every iteration's prediction, the
 correlation block and the update operator as autograd nodes on this library's kernels.
 """
 import itertools
+import math
 import os
 import warnings
 import threading
@@ -75,6 +76,15 @@ _GRAPH_LOCK = threading.Lock()
 _HANDOVER = threading.local()
 
 
+class _RetryForward(_ffi.DktError):
+    """Raised by RAFTStereo.iterate when the pair has to be computed again (the loop has switched form or scales)."""
+
+
+_NONFINITE = ("RAFTStereo.forward produced non-finite disparities: an activation left the range of the "
+              "split-fp16 convolutions (or the inputs were not finite).  Run one forward under "
+              "dkt_stereo_amd.conv.calibrate() to set per-layer exponents, or use conv.set_backend('miopen').")
+
+
 class _Shadow:
     """One persistent copy of a model on one device of an nn.DataParallel group, and the one thread that drives it.
 
@@ -112,8 +122,8 @@ class _Shadow:
         for a, b in zip(master.modules(), self.model.modules()):
             b.training = a.training                                  # freeze_bn() and eval() of the master
         for k, v in master.__dict__.items():                         # switches set on the instance (use_hip_graph, ...)
-            if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str)):
-                setattr(self.model, k, v)
+            if not k.startswith("_") and k != "training" and isinstance(v, (bool, int, float, str, tuple, type(None))):
+                setattr(self.model, k, v)                             # (tuple / None: precision_schedule)
 
     def _run(self, master, backend, ready, autocast, args, kwargs):
         torch.cuda.set_device(self.device)
@@ -138,6 +148,12 @@ class _Shadow:
             autocast = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
             out, done = self.pool.submit(self._run, master, _conv.get_backend(), ready, autocast, args, kwargs).result()
             caller.wait_event(done)
+            # the results were allocated on the worker's (default) stream and are consumed on the caller's: the caching
+            # allocator must not hand their blocks out again while the caller's stream still reads them
+            for t in (out.values() if isinstance(out, dict) else out if isinstance(out, (tuple, list)) else [out]):
+                for u in (t if isinstance(t, (tuple, list)) else [t]):
+                    if torch.is_tensor(u) and u.is_cuda:
+                        u.record_stream(caller)
         return out
 
 
@@ -226,11 +242,14 @@ class RAFTStereo(nn.Module):
     #: run fnet and cnet on two HIP streams (DKT_ENCODER_STREAMS=0 disables)
     encoder_streams = os.environ.get("DKT_ENCODER_STREAMS", "1") != "0"
 
+    #: enqueue the context encoder's full-resolution stage before the feature encoder (DKT_CNET_FIRST=0: after it, as rounds 2-5)
+    cnet_first = os.environ.get("DKT_CNET_FIRST", "1") != "0"
+
     #: replay the encoder pass (normalisation, fnet || cnet, context split: ~110 launches, two streams) from a
     #: captured HIP graph as well: launched eagerly, the host needs 2.5 ms to enqueue fnet before cnet's first
     #: kernel can start, and ~0.3 ms of launch gaps precede the first convolution.  Opt-in (attribute graph_encoders): at
     #: 736x1248 the encoders are GPU-bound and the replay measured no faster (9.63 vs 9.45 ms); it pays on small images
-    graph_encoders = False
+    graph_encoders = os.environ.get("DKT_GRAPH_ENCODERS", "0") == "1"
 
     def _encoder_fingerprint(self):
         fp = [(_conv.get_backend(), _extractor.FUSE_ENCODER, self.encoder_streams)]
@@ -245,11 +264,26 @@ class RAFTStereo(nn.Module):
                     fp.append(("bn", id(m), m.training))
         return tuple(fp)
 
+    @property
+    def _mixed(self):
+        """args.mixed_precision (raft_stereo.py:95,156: fp16 autocast around the encoders and the update block; default True on
+        the DKT teachers, tools/ft_dkt.py:317).  Here: every convolution of the encoders and of the refinement loop at ONE fp16
+        MFMA product per block (weights and activations rounded to fp16, fp32 accumulation and fp32 tensors between the
+        layers -- at least the precision autocast keeps); correlation volume, lookup and up-sampling stay fp32, as the
+        reference's `.float()` (raft_stereo.py:118-120) makes them.  False (base.json): the fp32-class parity path."""
+        return bool(getattr(self.args, "mixed_precision", False))
+
     # -- pieces of the reference forward, split so the hot path can be timed alone --
     def encode(self, image1, image2):
         """raft_stereo.py:91-116: normalisation, encoders, context split.  The returned hidden states and context terms are
         valid until the next encode() or iterate() on this thread: once the captured loop exists for this shape they ARE
         its state buffers (adopt_encoder_outputs; with graph_encoders the captured pass's static outputs)."""
+        if self._mixed and image1.is_cuda and _conv.get_backend() == "f16x3" and not torch.is_grad_enabled():
+            with _conv.use_backend("f16"):
+                return self._encode_any(image1, image2)
+        return self._encode_any(image1, image2)
+
+    def _encode_any(self, image1, image2):
         if (self.use_hip_graph and self.graph_encoders and not getattr(self, "_is_replica", False) and image1.is_cuda and image1.dtype == torch.float32
                 and image2.dtype == torch.float32 and image1.shape == image2.shape
                 and not torch.is_grad_enabled() and not _conv.calibrating()):
@@ -354,10 +388,15 @@ class RAFTStereo(nn.Module):
             main = torch.cuda.current_stream(image1.device)
             side = _side_stream(image1.device)
             side.wait_stream(main)
+            # The host needs ~2 ms to enqueue the feature encoder's ~45 launches.  When the previous pair has been waited for
+            # (check_finite: the default mode) the device would run the feature encoder's chain ALONE for that long -- its
+            # statistics reductions and finalize launches leave most CUs idle -- so the context encoder's full-resolution
+            # stage (5 launches, ~1.1 ms of work) goes on the main queue first (round 6: value_default_mode)
+            begun = self.cnet._trunk_begin(image1) if self.cnet_first else None
             with torch.cuda.stream(side):
                 fmap1, fmap2 = split(self.fnet(fnet_in))
                 self._prebuild(image1, fmap1, fmap2)
-            cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
+            cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post, begun=begun)
             main.wait_stream(side)
         else:
             self._prebuilt = None
@@ -664,14 +703,19 @@ class RAFTStereo(nn.Module):
         lp = st.get("c8")
         if lp is None:
             lp = st["c8"] = loop_c8.C8Loop(self, st)
+        st["c8_ran"] = True
         if "flow" not in st:
             b, _, h, w = st["coords1"].shape
             st["feat"], st["flow"] = self.update_block.encoder.new_feature_buffer(b, h, w, st["coords1"].device)
         torch.sub(st["coords1"], st["coords0"], out=st["flow"])
         ub = self.update_block
         from . import conv_c8
-        if self.precision_schedule is not False:          # (False: leave the loop's own setting alone)
+        if self.precision_schedule is not False:          # (False: whatever DKT_C8_SCHEDULE says, else fp32-class)
             lp.schedule = self.precision_schedule
+        elif self._mixed:
+            lp.schedule = (iters, 0)                      # args.mixed_precision: one fp16 product per block throughout
+        else:
+            lp.schedule = loop_c8.SCHEDULE
         plan = lp.plan(iters)                # MFMA passes per unit: 3 throughout unless a precision schedule is set
         with harness(inplace_state=True, side_stream=False):
             if not lp.calibrated:
@@ -781,7 +825,63 @@ class RAFTStereo(nn.Module):
 
     def iterate(self, fmap1, fmap2, net_list, inp_list, iters, flow_init=None):
         """The hot path, raft_stereo.py:118-183 in test_mode: correlation build,
-        then `iters` x (lookup, update block), then convex upsampling."""
+        then `iters` x (lookup, update block), then convex upsampling.  With `check_finite` (the default) the result's
+        post-conditions are verified here, for every entry point: a flag time-out or activations that left the
+        C8S scale window raise _RetryForward (a DktError) after the loop has fallen back / rescaled -- forward() repeats the
+        pair, a direct caller calls encode() + iterate() again --, a non-finite result raises DktError."""
+        st = self._graph_state
+        if st is not None:
+            st["c8_ran"] = False
+        flow, flow_up = self._iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+        if self.check_finite and flow_up.is_cuda:
+            self._verify(flow_up)
+        return flow, flow_up
+
+    def _verify(self, flow_up):
+        st = self._graph_state
+        lp = st.get("c8") if (st is not None and st.get("c8_ran")) else None
+        if lp is None:
+            if not bool(torch.isfinite(flow_up).all()):
+                raise _ffi.DktError(_NONFINITE)
+            return
+        s = lp.status(flow_up)               # one launch, one host synchronisation (csrc/status.hip)
+        if s.err:
+            # A fused ConvGRU (bit 0) or chain (bit 1) launch gave up waiting for a neighbour tile (csrc/gru_c8.hip: its
+            # blocks were not all resident -- another process or model on this device): this result is wrong.  The word is
+            # cleared, the loop leaves that form for good and the pair is computed again (ADVICE r04).
+            if getattr(lp, "timed_out", 0) & s.err:
+                raise _ffi.DktError("the refinement loop reported a flag time-out in a form that had already been switched off "
+                                    "(csrc/gru_c8.hip, conv_c8.hip)")
+            lp.timed_out = getattr(lp, "timed_out", 0) | s.err
+            warnings.warn("dkt_stereo_amd: a %s launch timed out waiting for a neighbour tile; falling back to separate "
+                          "launches for this model (one fused-GRU model per device)"
+                          % ("fused ConvGRU" if s.err & 1 else "chain"))
+            lp.on_error_word(s.err)
+            raise _RetryForward("flag time-out")
+        if lp.calibrated and not (s.finite and s.ranges_ok):
+            # this pair's activations left the window the C8S scales were picked for: new scales, repeat the pair.  From the
+            # maxima this pass left behind when they are all finite (no trial run); a trial run of the loop otherwise
+            lp.recalibrations += 1
+            if s.finite and all(math.isfinite(v) for v in s.maxima.reshape(-1).tolist()):
+                lp.rescale_from(s.maxima)
+                lp.calibrations += 1
+            else:
+                lp.calibrated = False
+            raise _RetryForward("activation scales")
+        if not s.finite:
+            raise _ffi.DktError(_NONFINITE)
+
+    def _iterate(self, fmap1, fmap2, net_list, inp_list, iters, flow_init=None):
+        if self._mixed and fmap1.is_cuda and _conv.get_backend() == "f16x3" and not torch.is_grad_enabled():
+            from . import loop_c8
+            c8 = (self.use_c8 and self.use_hip_graph and iters >= 3 and not getattr(self, "_is_replica", False)
+                  and self.args.corr_implementation == "reg" and loop_c8.eligible(self, net_list[0].shape))
+            if not c8:                   # (the C8S loop takes its one-product schedule itself, see _iterate_c8)
+                with _conv.use_backend("f16"):
+                    return self._iterate_fp(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+        return self._iterate_fp(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+
+    def _iterate_fp(self, fmap1, fmap2, net_list, inp_list, iters, flow_init=None):
         args = self.args
         n = args.n_gru_layers
         # conv.calibrate() records activation ranges with a host synchronisation per layer: the plain loop (no stream capture,
@@ -882,35 +982,13 @@ class RAFTStereo(nn.Module):
 
     def _forward_test(self, image1, image2, iters, flow_init):
         with GPU_GUARD.shared():                      # another thread's graph capture waits for this pass, and vice versa
-            fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
-            flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
-            finite = (not self.check_finite) or bool(torch.isfinite(flow_up).all())
-            lp = (self._graph_state or {}).get("c8") if self.check_finite else None
-            if lp is not None and lp.take_error():
-                # A fused ConvGRU launch gave up waiting for a neighbour tile (csrc/gru_c8.hip: its blocks were not all
-                # resident -- another process or model on this device): that forward is wrong.  The word is cleared, the
-                # loop takes the two-launch form from here on and the pair is computed again.
-                warnings.warn("dkt_stereo_amd: the fused ConvGRU launch timed out waiting for a neighbour tile; "
-                              "falling back to the two-launch form for this model (one fused-GRU model per device)")
-                lp.disable_fused_gru()
+            for _ in range(4):
                 fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
-                flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
-                finite = bool(torch.isfinite(flow_up).all())
-                if lp.take_error():
-                    raise _ffi.DktError("the ConvGRU launch reported a flag time-out in the two-launch form (csrc/gru_c8.hip)")
-            if lp is not None and lp.calibrated and (not finite or not lp.ranges_ok()):
-                # this pair's activations left the window the C8S scales were picked for: pick again, repeat the forward
-                lp.calibrated = False
-                gs = self._graph_state
-                if gs is not None and net_list[0].data_ptr() == gs["net"][0].data_ptr():
-                    # (the encoder pass wrote the hidden states into the loop's own buffers, where the loop has updated
-                    # them in place: produce them again)
-                    fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
-                flow, flow_up = self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
-                finite = bool(torch.isfinite(flow_up).all())
-        if not finite:
-            raise _ffi.DktError(
-                "RAFTStereo.forward produced non-finite disparities: an activation left the range of the "
-                "split-fp16 convolutions (or the inputs were not finite).  Run one forward under "
-                "dkt_stereo_amd.conv.calibrate() to set per-layer exponents, or use conv.set_backend('miopen').")
-        return flow, flow_up
+                try:
+                    return self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+                except _RetryForward:
+                    # (the loop has changed form or scales; the encoder pass may have written the hidden states into the
+                    # loop's own buffers, where the loop has updated them in place: produce them again)
+                    continue
+        raise _ffi.DktError("RAFTStereo.forward: the refinement loop asked for a fourth repeat of one pair "
+                            "(flag time-outs / activation scales that do not settle)")

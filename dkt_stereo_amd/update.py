@@ -661,6 +661,14 @@ class BasicMultiUpdateBlockIGEV(BasicMultiUpdateBlock):
             nn.Conv2d(hidden_dims[2], 32, 3, padding=1),
             nn.ReLU(inplace=True))
 
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel's per-forward copy knows the block it was made from: igev_loop.igev_iterate hands a replica's loop
+        to a persistent per-device copy of THAT block (igev_loop._ShadowBlock), as raft_stereo.RAFTStereo does for itself."""
+        import weakref
+        replica = super()._replicate_for_data_parallel()
+        replica._dp_master = weakref.ref(self)
+        return replica
+
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True,
                 update=True, need_mask=True):
         if self._wants_grad(net, inp, corr, disp):

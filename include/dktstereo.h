@@ -487,7 +487,7 @@ int dkt_conv2d_c8_pair(const dkt_conv_c8_desc *d0, const dkt_conv_c8_desc *d1, i
  * core/update.py:27-31].  A stage-1 tile waits for the flags of the stage-0 tiles under its patch instead of a kernel
  * boundary (gru_c8.hip's protocol).  cfg0 / cfg1: tile shapes of the stages, (4, 3) or (4, 4).
  *   flags       : dkt_conv2d_c8_chain_flag_words(d0a, cfg0, 1 or 2) zero-initialised words owned by this pair of layers;
- *   err_word    : optional, set to 2 when a wait timed out (results invalid);
+ *   err_word    : optional, bit 1 (value 2) is OR-ed in when a wait timed out (results invalid);
  *   max_blocks  : bound on the launch's blocks (0 = what the device holds).  Every block of a chain launch must stay
  *                 resident while it may wait: chains that can run AT THE SAME TIME on different streams must fit the device
  *                 together (256 each for two chains on MI355X);
@@ -508,7 +508,7 @@ int dkt_conv2d_c8_chain(const dkt_conv_c8_desc *d0a, const dkt_conv_c8_desc *d0b
  *   bz, br, bq : the three biases in the reference's channel order;  scale_* : 1 / (weight scale * activation scale);
  *   flags : dkt_gru_c8_flag_words(B, H, W) zero-initialised 32-bit words owned by this (operator, shape) pair -- every
  *           launch increments them, they must not be shared with a launch of another shape or written by the caller;
- *   err_word (optional, device memory): set to 1 if a neighbour wait timed out (results are then invalid).
+ *   err_word (optional, device memory): bit 0 (value 1) is OR-ed in if a neighbour wait timed out (results are then invalid).
  * DKT_E_UNSUPPORTED when the device cannot hold the launch's tiles the way the flags need (fall back to two
  * dkt_conv2d_c8 launches with epilogues 1 and 2). */
 typedef struct dkt_gru_c8_desc {
@@ -611,6 +611,25 @@ int dkt_corr1d_lookup_conv1x1_c8(const float *const *skew, const float *coords_x
                                  const float *weight, const float *bias, void *out_c8, long out_c8_bstride_bytes,
                                  int out_c8_ch0, float act_scale, int B, int H, int W1, int W2, int L, int r, int Cout,
                                  int relu, int device, void *stream);
+
+/* ---- round 6: the post-conditions of one pair, in one launch ----------------------------------------------------------
+ * The reference's forward (meta_arch/raft_stereo/raft_stereo.py:85-187, igev_stereo.py:192-210) is plain fp32 and needs no
+ * check; this implementation equals it only while (i) nothing overflowed the split-fp16 operands, (ii) no fused ConvGRU /
+ * chain launch timed out on a neighbour flag (dkt_gru_c8: `err`), (iii) the C8S tensors that follow the input's magnitude
+ * still sit in the window their scales were picked for.  dkt_loop_status gathers all three for the caller's ONE host read:
+ *   status[0]         = *err_word (0 when err_word is NULL); the word is cleared (atomic exchange)
+ *   status[1]         = 1 when finite_src[0 .. finite_n) holds an Inf or a NaN
+ *   status[2 + 2 j]   = max over the body channels of C8S tensor j of the fp16 BIT PATTERN of |hi| (0x7c00 = Inf, above = NaN)
+ *   status[3 + 2 j]   = the same over its `tail` trailing channels (0 when tail = 0)
+ * status: 2 + 2 njobs words, zeroed by the call (stream-ordered).  njobs <= DKT_STATUS_MAX_JOBS. */
+#define DKT_STATUS_MAX_JOBS 8
+typedef struct dkt_c8_range_job {
+    const void *t; long bstride_bytes;          /* C8S tensor (B, C channels, H x W) */
+    int B, C, H, W;
+    int tail;                                   /* trailing channels reported separately (their own scale) */
+} dkt_c8_range_job;
+int dkt_loop_status(const dkt_c8_range_job *jobs, int njobs, const float *finite_src, long finite_n, int *err_word,
+                    unsigned *status, int device, void *stream);
 
 #ifdef __cplusplus
 }

@@ -7,8 +7,9 @@
   cfg4  RAFT-Stereo batch 8 per GPU (the per-GPU share of batch 64 over 8 GPUs), 1 GPU
   cfg5  GwcNet 544x960: gwc (40 groups) + concat (2x12) volume, D=48 planes, one fused buffer
 
-    python tools/bench_configs.py [cfg3] [cfg4] [cfg5]
-One JSON object per line.
+    python tools/bench_configs.py [cfg3] [cfg4] [cfg5] [--skip-cpu-baseline]
+One JSON object per line; cfg3 and cfg5 carry `roofline` (the dominant kernel of the path, timed live) and `cpu_baseline` (the
+oracle on this host's cores, bounded sample) as bench.py's line does, and the true `dtype`.
 """
 import json
 import os
@@ -68,11 +69,88 @@ def cfg3():
         return igev_iterate(blk, cache["geo"], disp0, coords, net0, inp, iters, cache=cache)[0]   # :199-210
 
     t = sync_time(pair, 3, 2)
+    # roofline: the dominant kernel is the fused ConvGRU launch (dkt_gru_c8_pair: gru04 with gru16 of the next iteration riding
+    # along), timed where the loop runs it -- the loop's units as plain launches (C8Loop.prologue / unit, what calibrate() runs),
+    # an event pair around every fused launch on its stream
+    from dkt_stereo_amd import conv_c8 as dc8
+    from dkt_stereo_amd.update import harness
+    st = cache["state"]
+    lp = getattr(st, "c8", None)
+    roof = None
+    if lp is not None and lp.fuse_gru:
+        real, events, used = dc8.gru_launch, [], []
+
+        def timed(d0, d1=None, err=None, ref=None):
+            if d1 is None or d0.H != H:
+                return real(d0, d1, err=err, ref=ref)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ok = real(d0, d1, err=err, ref=ref)
+            b.record()
+            if ok:
+                events.append((a, b))
+                used.append((sum(d0.x_channels[i] for i in range(d0.nx)), d1.H, d1.W, sum(d1.x_channels[i] for i in range(d1.nx))))
+            return ok
+
+        d = dict(net=st.net, inp=st.inp, disp=st.disp, coords=st.coords, geo_fn=st.geo_fn)
+        dc8.gru_launch = timed
+        try:
+            with harness(inplace_state=True, side_stream=False):
+                st.disp.copy_(disp0)
+                for dst, src in zip(st.net, net0):
+                    dst.copy_(src)
+                lp.prologue(d)
+                for k in range(iters):
+                    lp.unit(d, last=(k + 1 == iters))
+        finally:
+            dc8.gru_launch = real
+        torch.cuda.synchronize()
+        empty = []
+        for _ in range(32):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()
+            empty.append((a, b))
+        torch.cuda.synchronize()
+        over = sorted(x.elapsed_time(y) for x, y in empty)[16]
+        ms = [max(a.elapsed_time(b) - over, 1e-6) for a, b in events]
+        xc, h2, w2, xc2 = used[0]
+        flops = 2.0 * H * W * (128 + xc) * 9 * 384 + 2.0 * h2 * w2 * (128 + xc2) * 9 * 384
+        avg = sum(ms) / len(ms)
+        ach = flops / (avg * 1e-3) / 1e12
+        roof = {"kernel": "gru_c8_kernel (dkt_gru_c8_pair): gru04 z|r %d->256 + gates + q %d->128 + state update @%dx%d, gru16 "
+                          "(%d->256, %d->128 @%dx%d) riding along" % (128 + xc, 128 + xc, H, W, 128 + xc2, 128 + xc2, h2, w2),
+                "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "mfma_passes": 3,
+                "mfma_issue_frac": 3 * ach / 2500.0, "algorithmic_flops_per_launch": flops, "avg_launch_us": 1e3 * avg,
+                "launches_timed": len(ms), "traffic": None,
+                "traffic_note": "not measured for this loop (RAFT's launch of the same kernel: profiles/r05_hbm_traffic.txt)"}
+    # CPU baseline: the oracle's restatement of igev_stereo.py:192-210 (pinned by tests/golden/igev_loop.npz) on this host's
+    # cores, bounded sample: pyramids once, `n_cpu` iterations, extrapolated to 32
+    cpu = None
+    if "--skip-cpu-baseline" not in sys.argv:
+        from oracle import torch_oracle as to
+        sd = {"update_block." + k: v.cpu() for k, v in blk.state_dict().items()}
+        n_cpu = 4
+        args_cpu = (sd, dict(cfg), ml.cpu(), mr.cpu(), geo.cpu(), disp0.cpu(), [t.cpu() for t in net0], [[t.cpu() for t in s_] for s_ in inp])
+        to.igev_iterations(*args_cpu, 1)
+        t0 = time.perf_counter()
+        to.igev_iterations(*args_cpu, 1)
+        t1 = time.perf_counter()
+        to.igev_iterations(*args_cpu, n_cpu)
+        t2 = time.perf_counter()
+        per_iter = max((t2 - t1) - (t1 - t0), 1e-9) / (n_cpu - 1)
+        pair_s = (t1 - t0) + (iters - 1) * per_iter
+        cpu = {"value": 1.0 / pair_s, "unit": "pairs/s (loop)", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "geometry pyramids once + %d of %d iterations timed (%.2f s/iter), extrapolated" % (n_cpu, iters, per_iter),
+               "s_per_pair": pair_s}
     print(json.dumps({"config": "cfg3 IGEV-Stereo 736x1248 (184x312 @1/4), gwc volume + geometry-encoding "
                                 "pyramids + 32 x (geo lookup + IGEV update block); feature/3-D aggregation "
                                 "networks excluded (not constructible offline)",
+                      "metric": "stereo pairs/sec (refinement loop from the match features / geometry volume on)",
+                      "value": 1.0 / t, "unit": "pairs/s", "higher_is_better": True,
                       "ms_per_pair_loop": 1e3 * t, "ms_per_iter": 1e3 * t / iters, "loop_pairs_per_s": 1.0 / t,
-                      "dtype": "f32", "data": "synthetic"}), flush=True)
+                      "dtype": "f32 io/accumulate; convolution products = 3x fp16-split MFMA (22-bit operands); geometry lookup, "
+                               "gwc volume, correlation exact fp32",
+                      "roofline": roof, "cpu_baseline": cpu, "data": "synthetic"}), flush=True)
 
 
 @torch.no_grad()
@@ -88,7 +166,8 @@ def cfg4():
     t = sync_time(lambda: m(i1, i2, iters=32, test_mode=True), 2, 2)
     print(json.dumps({"config": "cfg4 RAFT-Stereo 736x1248, 32 iters, batch 8 on one GPU (per-GPU share of "
                                 "batch 64 over 8 GPUs)", "ms_per_batch": 1e3 * t, "pairs_per_s": B / t,
-                      "dtype": "f32", "data": "synthetic"}), flush=True)
+                      "dtype": "f32 io/accumulate; convolution products = 3x fp16-split MFMA (22-bit operands); lookup / correlation "
+                               "exact fp32 (roofline and cpu_baseline: `bench.py --batch 8`)", "data": "synthetic"}), flush=True)
 
 
 @torch.no_grad()
@@ -127,15 +206,61 @@ def cfg5():
     fR = {k: v[1:] for k, v in f.items()}
     vol = stage("volume_ms", lambda: m.build_volume(fL, fR))
     stage("aggregation_softargmin_ms", lambda: m.cost_regularization(vol))
+    # roofline: the path's own kernel here is the group-wise correlation on the matrix pipe (dkt_gwc_volume_mfma inside the fused
+    # gwc + concat buffer): HBM-bound by its plane stores.  Algorithmic bytes = both feature maps read once + every plane written
+    # once; launch time from a graph of back-to-back launches (the kernel is stand-alone in the pipeline too)
+    vol_g = torch.empty(1, 40, 48, H, W, device=DEV)
+    from dkt_stereo_amd import submodule as sm
+
+    def one():
+        sm.build_gwc_volume(fl, fr, 48, 40)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    gl = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gl):
+        for _ in range(10):
+            one()
+    gl.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        gl.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    gwc_ms = e0.elapsed_time(e1) / 100.0
+    alg = 2 * 320 * H * W * 4 + 40 * 48 * H * W * 4
+    del vol_g
+    roof = {"kernel": "gwc_mfma_kernel (dkt_gwc_volume_mfma): 320 channels / 40 groups, 48 planes @%dx%d, exact-fp32 MFMA" % (H, W),
+            "bound": "hbm", "achieved": alg / (gwc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+            "frac": alg / (gwc_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": alg, "avg_launch_us": 1e3 * gwc_ms,
+            "launches_timed": 100, "traffic": None, "traffic_note": "PMC passes of this kernel: profiles/r03_gwc_mfma.txt"}
+    cpu = None
+    if "--skip-cpu-baseline" not in sys.argv:
+        from oracle import torch_oracle as to
+        a_ = (fl.cpu(), fr.cpu(), cl.cpu(), cr.cpu())
+        to.gwc_volume(a_[0], a_[1], 48, 40)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.cat((to.gwc_volume(a_[0], a_[1], 48, 40), to.concat_volume(a_[2], a_[3], 48, True)), 1)
+        tc = (time.perf_counter() - t0) / 3
+        cpu = {"value": 1.0 / tc, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": "gwc (40 groups) + concat volume + cat, 3 repetitions, %.3f s each" % tc, "us_per_volume": 1e6 * tc}
     print(json.dumps({"config": "cfg5 GwcNet 544x960 (136x240 @1/4): gwc volume 320ch/40 groups + concat volume "
                                 "2x12ch, 48 planes -> (1,64,48,136,240); end to end with 3-D aggregation on the vendor library",
+                      "metric": "cost volumes/sec (gwc + concat into one buffer)", "value": 1.0 / t_fused, "unit": "volumes/s",
+                      "higher_is_better": True,
                       "us_separate_plus_cat": 1e6 * t_sep, "us_fused_buffer": 1e6 * t_fused,
                       "output_GB_per_s_fused": out_bytes / t_fused / 1e9,
                       "e2e_ms_per_pair": 1e3 * t_e2e, "e2e_pairs_per_s": 1.0 / t_e2e, "e2e_stages": feats,
-                      "dtype": "f32", "data": "synthetic"}), flush=True)
+                      "dtype": "f32: volumes exact fp32 (group-wise correlation on the fp32 matrix pipe); feature network: "
+                               "convolution products = 3x fp16-split MFMA (22-bit operands); 3-D aggregation: vendor fp32",
+                      "roofline": roof, "cpu_baseline": cpu, "data": "synthetic"}), flush=True)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg3", "cfg4", "cfg5"]
     for w in which:
         {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[w]()

@@ -22,7 +22,7 @@ mk = lambda cin, cout: torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
 @torch.no_grad()
 def run(B):
     torch.manual_seed(0)
-    print("\n## batch %d (us per launch; us per pair; algorithmic TFLOP/s)" % B)
+    print("\n## batch %d (us per launch; us per pair; algorithmic TFLOP/s; frac of the 2.5 PF fp16 peak)" % B)
 
     def rep(name, fn, gflop):
         try:
@@ -30,7 +30,8 @@ def run(B):
         except Exception as e:          # shape not covered by this tile shape
             print("%-58s unsupported (%s)" % (name, str(e)[:40]))
             return
-        print("%-58s %9.1f %8.1f %7.1f" % (name, us, us / B, gflop * B / us * 1e-3), flush=True)
+        tf = gflop * B / us * 1e3                       # GFLOP / us = PFLOP/s
+        print("%-58s %9.1f %8.1f %7.1f %6.3f" % (name, us, us / B, tf, tf / 2500.0), flush=True)
 
     acts = lambda n, h, w, c=128: [c8.pack(torch.randn(B, c, h, w, device=DEV)) for _ in range(n)]
     hc = acts(1, H, W)[0]
