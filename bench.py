@@ -291,6 +291,15 @@ def main():
             step()
         sync()
         mine_default = time.perf_counter() - td0
+        # (and the unchecked steps once more behind it: the two modes are timed back to back on a device whose clocks drift with
+        # its temperature -- `value_unchecked_again` shows how much of the difference is the order of the regions)
+        model.check_finite = False
+        tr0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        mine_again = time.perf_counter() - tr0
+        model.check_finite = True
         # (gloo carries host tensors; RCCL device tensors)
         elapsed = torch.tensor([mine, mine_default], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         per_rank = [mine]
@@ -581,6 +590,7 @@ def main():
         # finiteness, scale window -- are read once behind it: `error_word`); the same steps in the product's default mode:
         "value_default_mode": world * B * args.steps / elapsed_default,
         "ms_per_step_default_mode": 1e3 * elapsed_default / args.steps,
+        "value_unchecked_again": world * B * args.steps / mine_again,
         "error_word": error_word,
         "recalibrations": (distinct or {}).get("recalibrations"),
         "distinct_pairs": distinct,

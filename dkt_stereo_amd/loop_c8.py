@@ -222,40 +222,55 @@ class C8Loop:
         from . import conv_c8
         return "corr" in st and conv_c8.motion_front_supported(st["corr"], self.ub.encoder)
 
-    def capture(self, st, capture_graph, passes=3):
-        """Captures one unit, the final unit, and GRAPH_UNITS units back to back (capturing records, it does not execute) --
-        with the fused front once per parity of the coordinate buffer the sequence starts from -- at `passes` MFMA products per
-        block (graphs are kept per (passes, parity): a precision schedule replays units of several kinds)."""
-        with c8.passes(passes):
-            self._mask(st)      # eager once: the final unit's own layers are packed (with the calibrated scales) outside the capture
-        torch.cuda.synchronize()
-        keep = self.par
+    def _captured(self, kind, passes, par, st, capture_graph):
+        """The captured graph of `kind` ("one" unit, the "last" unit of a pair, "n" = GRAPH_UNITS units back to back) at `passes`
+        MFMA products per block, starting from coordinate-buffer parity `par` -- captured on first use (round 6: a pair touches
+        four of the six (kind, parity) combinations, and a recalibration pays for every capture it triggers).  Capturing
+        records, it does not execute."""
         if self.graph is None:
             self.graph, self.graph_last, self.graph_n = {}, {}, {}
             self.pinned = []             # the packed weight images the captured launches point to (conv_c8.pin_packs)
-        for p in ((0, 1) if self.front else (0,)):
-            def cap(fn):
-                self.par = p
-                g = torch.cuda.CUDAGraph()
-                with capture_graph(g), c8.pin_packs(self.pinned), c8.passes(passes):
-                    fn()
-                return g
-            with _ffi.launch_log() as names:
-                self.graph[passes, p] = cap(lambda: self.unit(st))
-            self.unit_launches = list(names)          # the dispatches of one captured unit (tests pin their number)
-            self.graph_last[passes, p] = cap(lambda: self.unit(st, last=True))
-            if GRAPH_UNITS > 1:
-                self.graph_n[passes, p] = cap(lambda: [self.unit(st) for _ in range(GRAPH_UNITS)])
+        store = {"one": self.graph, "last": self.graph_last, "n": self.graph_n}[kind]
+        g = store.get((passes, par))
+        if g is not None:
+            return g
+        if not getattr(self, "_mask_packed", None) == (passes, id(self.pinned)):
+            with c8.passes(passes):
+                self._mask(st)      # eager once: the final unit's own layers are packed (with the calibrated scales) outside the capture
+            self._mask_packed = (passes, id(self.pinned))
+        torch.cuda.synchronize()
+        keep = self.par
+        self.par = par
+        g = torch.cuda.CUDAGraph()
+        with _ffi.launch_log() as names:
+            with capture_graph(g), c8.pin_packs(self.pinned), c8.passes(passes):
+                if kind == "one":
+                    self.unit(st)
+                elif kind == "last":
+                    self.unit(st, last=True)
+                else:
+                    for _ in range(GRAPH_UNITS):
+                        self.unit(st)
+        if kind == "one" or (kind == "n" and self.unit_launches is None):
+            names = list(names)
+            self.unit_launches = names if kind == "one" else names[:len(names) // GRAPH_UNITS]   # (tests pin their number)
         self.par = keep
+        store[passes, par] = g
+        return g
+
+    def capture(self, st, capture_graph, passes=3):
+        """Every kind of captured unit at `passes` products, both parities (what rounds 4-5 did up front; tools and tests)."""
+        for p in ((0, 1) if self.front else (0,)):
+            for kind in ("one", "last") + (("n",) if GRAPH_UNITS > 1 else ()):
+                self._captured(kind, passes, p, st, capture_graph)
 
     def replay(self, plan, st, capture_graph, last=False):
         """One captured unit per entry of `plan` (its MFMA passes); `last`: the final entry is the pair's final unit."""
         plan = list(plan)
-        for p in sorted(set(plan)):
-            if self.graph is None or (p, 0) not in self.graph:
-                self.capture(st, capture_graph, p)          # (first use of this kind of unit: once per state)
         tail = plan.pop() if last else None
         step = GRAPH_UNITS if GRAPH_UNITS % 2 == 0 or not self.front else 0      # (an odd run of units would end on the other parity)
+        if GRAPH_UNITS <= 1:
+            step = 0
         i = 0
         while i < len(plan):
             p = plan[i]
@@ -263,17 +278,19 @@ class C8Loop:
             while i + run < len(plan) and plan[i + run] == p:
                 run += 1
             n = run
-            while self.graph_n and step and n >= step:
-                self.graph_n[p, self.par].replay()
+            while step and n >= step:
+                self._captured("n", p, self.par, st, capture_graph).replay()
                 n -= step
             for _ in range(n):
-                self.graph[p, self.par].replay()
+                self._captured("one", p, self.par, st, capture_graph).replay()
                 if self.front:
                     self.par ^= 1
             i += run
         if last:
-            self.graph_last[tail, self.par].replay()
+            self._captured("last", tail, self.par, st, capture_graph).replay()
             self.par = 0                 # (the final unit leaves the coordinate in st["coords1"])
+        if self.graph is None:           # (an empty plan: nothing captured, but "a unit has run eagerly" must not repeat)
+            self.graph, self.graph_last, self.graph_n = {}, {}, {}
 
     _tail_channels = 2                   # flow (x, y) behind the 126 motion features (core/update.py:85)
 

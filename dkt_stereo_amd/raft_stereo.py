@@ -242,6 +242,9 @@ class RAFTStereo(nn.Module):
     #: run fnet and cnet on two HIP streams (DKT_ENCODER_STREAMS=0 disables)
     encoder_streams = os.environ.get("DKT_ENCODER_STREAMS", "1") != "0"
 
+    #: forward(): the join of the feature encoder's stream is left to the loop's prologue (DKT_DEFER_FNET_JOIN=0: encode() joins)
+    defer_fnet_join = os.environ.get("DKT_DEFER_FNET_JOIN", "1") != "0"
+
     #: enqueue the context encoder's full-resolution stage before the feature encoder (DKT_CNET_FIRST=0: after it, as rounds 2-5)
     cnet_first = os.environ.get("DKT_CNET_FIRST", "1") != "0"
 
@@ -337,6 +340,8 @@ class RAFTStereo(nn.Module):
         return property(get, put)
 
     _prebuilt = _handover("prebuilt")        # the correlation block encode() has rebuilt for the pair at hand
+    _defer_join = _handover("defer")         # forward() lets encode() leave the feature encoder's stream un-joined ...
+    _pending_join = _handover("join")        # ... and this is that stream, for iterate() to join
     _static_ctx = _handover("static")        # encode()'s outputs when they are the captured pass's static tensors
     del _handover
 
@@ -397,7 +402,15 @@ class RAFTStereo(nn.Module):
                 fmap1, fmap2 = split(self.fnet(fnet_in))
                 self._prebuild(image1, fmap1, fmap2)
             cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post, begun=begun)
-            main.wait_stream(side)
+            if self._defer_join and self._prebuilt is not None and self.defer_fnet_join:
+                # forward(): the feature maps' only consumer -- the correlation build -- has already been enqueued on the
+                # feature encoder's stream; the loop's prologue forks ITS correlation-dependent half (lookup + motion encoder of
+                # iteration 0) onto that same stream and joins it itself, so the hidden-state half of the prologue (pack, gru32,
+                # gru16: ~0.4 ms) starts as soon as the context encoder is done instead of behind the feature encoder's tail
+                # (conv2, correlation build, skewed copy: ~0.35 ms).  iterate() joins wherever that does not hold.
+                self._pending_join = side
+            else:
+                main.wait_stream(side)
         else:
             self._prebuilt = None
             cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post)
@@ -697,8 +710,9 @@ class RAFTStereo(nn.Module):
     precision_schedule = False
     c8_eager = False
 
-    def _iterate_c8(self, st, iters):
-        """loop_c8.C8Loop: prologue, `iters` units (the first eagerly, one captured, the rest replayed), mask head."""
+    def _iterate_c8(self, st, iters, pending=None):
+        """loop_c8.C8Loop: prologue, `iters` units (the first eagerly, one captured, the rest replayed), mask head.
+        `pending`: the feature encoder's stream when encode() has left it un-joined (the correlation volume is being built on it)."""
         from . import loop_c8
         lp = st.get("c8")
         if lp is None:
@@ -717,6 +731,11 @@ class RAFTStereo(nn.Module):
         else:
             lp.schedule = loop_c8.SCHEDULE
         plan = lp.plan(iters)                # MFMA passes per unit: 3 throughout unless a precision schedule is set
+        # the prologue forks its correlation-dependent half onto _side_stream(slot 0) -- the very stream the volume is being built
+        # on -- and joins it: no other join is needed then.  Everything else (a trial run, a one-stream prologue) joins first
+        if pending is not None and not (lp.calibrated and loop_c8.FORK and loop_c8.PROLOGUE_FORK
+                                        and pending is _side_stream(st["coords1"].device, slot=0)):
+            self._join_encoder(pending)
         with harness(inplace_state=True, side_stream=False):
             if not lp.calibrated:
                 lp.calibrate(st, iters)      # activation scales from a trial run on this pair (state restored)
@@ -741,7 +760,7 @@ class RAFTStereo(nn.Module):
             from . import conv_c8
             return .25 * conv2d(conv_c8.conv2d_c8([lp.hc8[0]], ub.mask[0], relu=True, cfg=1), ub.mask[2])
 
-    def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init):
+    def _iterate_graphed(self, fmap1, fmap2, net_list, inp_list, iters, flow_init, pending=None):
         """Same arithmetic as the eager loop; iterations 2..iters-1 are replays of one
         captured HIP graph (~60 launches per iteration leave the CPU out of the loop)."""
         args = self.args
@@ -754,6 +773,9 @@ class RAFTStereo(nn.Module):
         st = self._graph_state
         prebuilt, self._prebuilt = self._prebuilt, None
         static, self._static_ctx = self._static_ctx, None
+        if st is None or st["key"] != key or prebuilt != (st["corr"], fmap1.data_ptr(), fmap2.data_ptr()):
+            self._join_encoder(pending)      # (the volume is built here, on this stream, from the feature maps)
+            pending = None
         if st is None or st["key"] != key:
             st = dict(key=key, graph=None, bound=None, fmap_shape=tuple(fmap1.shape))
             st["corr"] = CORR_IMPLEMENTATIONS[args.corr_implementation](
@@ -792,9 +814,10 @@ class RAFTStereo(nn.Module):
         if self.use_c8 and iters >= 3:
             from . import loop_c8
             if loop_c8.eligible(self, st["net"][0].shape):
-                up_mask = self._iterate_c8(st, iters)
+                up_mask = self._iterate_c8(st, iters, pending)
                 flow = st["coords1"] - st["coords0"]
                 return flow, self.upsample_flow(flow, up_mask)[:, :1]
+        self._join_encoder(pending)
         if self._can_pipeline() and self.rotate and self.pair_grus:
             up_mask = self._iterate_rotated(st, iters)
             flow = st["coords1"] - st["coords0"]
@@ -881,8 +904,13 @@ class RAFTStereo(nn.Module):
                     return self._iterate_fp(fmap1, fmap2, net_list, inp_list, iters, flow_init)
         return self._iterate_fp(fmap1, fmap2, net_list, inp_list, iters, flow_init)
 
+    def _join_encoder(self, pending):
+        if pending is not None:
+            torch.cuda.current_stream(pending.device).wait_stream(pending)
+
     def _iterate_fp(self, fmap1, fmap2, net_list, inp_list, iters, flow_init=None):
         args = self.args
+        pending, self._pending_join = self._pending_join, None      # (the feature encoder's stream, not joined yet: see _encode)
         n = args.n_gru_layers
         # conv.calibrate() records activation ranges with a host synchronisation per layer: the plain loop (no stream capture,
         # every iteration observed) serves it
@@ -890,7 +918,8 @@ class RAFTStereo(nn.Module):
         # loop would be re-captured each time -- they run the plain loop; graph replay needs ONE persistent module per device
         if (self.use_hip_graph and not getattr(self, "_is_replica", False) and not _conv.calibrating() and iters >= 3 and fmap1.is_cuda and args.corr_implementation == "reg"
                 and CORR_IMPLEMENTATIONS["reg"].__name__ == "CorrBlock1D"):
-            return self._iterate_graphed(fmap1, fmap2, net_list, inp_list, iters, flow_init)
+            return self._iterate_graphed(fmap1, fmap2, net_list, inp_list, iters, flow_init, pending)
+        self._join_encoder(pending)
         self._prebuilt = self._static_ctx = None       # (the plain loop builds its own volume: nothing of encode()'s hand-over survives it)
         corr_block = CORR_IMPLEMENTATIONS[args.corr_implementation]
         corr_fn = corr_block(fmap1, fmap2, radius=args.corr_radius, num_levels=args.corr_levels)
@@ -983,7 +1012,11 @@ class RAFTStereo(nn.Module):
     def _forward_test(self, image1, image2, iters, flow_init):
         with GPU_GUARD.shared():                      # another thread's graph capture waits for this pass, and vice versa
             for _ in range(4):
-                fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
+                self._defer_join = True
+                try:
+                    fmap1, fmap2, net_list, inp_list = self.encode(image1, image2)
+                finally:
+                    self._defer_join = None
                 try:
                     return self.iterate(fmap1, fmap2, net_list, inp_list, iters, flow_init)
                 except _RetryForward:

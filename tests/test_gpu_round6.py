@@ -158,7 +158,7 @@ def test_mixed_precision_flag(golden):
     _, got = on(i1, i2, iters=c["iters"], test_mode=True)
     lp = on._graph_state["c8"]
     assert lp.schedule == (c["iters"], 0) and set(lp.plan(c["iters"])) == {1}
-    assert {k[0] for k in lp.graph} == {1}                   # every captured unit is the one-product kind
+    assert {k[0] for d in (lp.graph, lp.graph_n, lp.graph_last) for k in d} == {1}                   # every captured unit is the one-product kind
     g = golden("raft_e2e")
     s = int(g[name + "/stride"])
     d_on = maxabs(got[:, :, ::s, ::s], g[name + "/flow_up"])
@@ -298,8 +298,35 @@ def test_calibration_stress_twenty_pairs():
              max(dist)))
     assert max(dist) <= 1e-3, dist
     assert model._graph_state["c8"] is lp                       # the same loop object served all of them
-    assert 1 <= rec <= 12                                       # disparities 1 ... 190: the 2^8 window is left, not on every pair
-    assert max(times) <= 8.0 * steady, (max(times), steady)     # a recalibrated forward: encoders twice, re-capture, the loop twice
+    assert rec <= 12                                            # (measured: 0 -- a 2^8 window around the calibration pair's maxima)
+    assert max(times) <= 3.0 * steady, (max(times), steady)
+    # A pair that does leave the window: an initial flow of -900 pixels (flow_init, raft_stereo.py:141-142) puts the flow
+    # features 2^8 above what the scales were picked for.  The forward rescales from the maxima that pass left behind (no trial
+    # run), re-captures and repeats the pair; going back to the first pair rescales again.
+    want0 = model(base[0], base[1], iters=iters, test_mode=True)[1].clone()
+    init = torch.zeros(1, 2, H // 4, W // 4, device=DEV)
+    init[:, 0] = -900.0
+    r1, c1 = lp.recalibrations, lp.calibrations
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, got = model(base[0], base[1], iters=iters, flow_init=init, test_mode=True)
+    torch.cuda.synchronize()
+    t_recal = time.perf_counter() - t0
+    assert lp.recalibrations == r1 + 1 and lp.calibrations == c1 + 1
+    fresh, _ = _raft()
+    _, want = fresh(base[0], base[1], iters=iters, flow_init=init, test_mode=True)
+    d_far = maxabs(got, want)
+    _, again = model(base[0], base[1], iters=iters, flow_init=init, test_mode=True)
+    assert lp.recalibrations == r1 + 1 and torch.equal(again, got)            # the new scales hold for this kind of pair
+    _, back = model(base[0], base[1], iters=iters, test_mode=True)
+    assert lp.recalibrations == r1 + 2
+    print("a pair 2^8 outside the window: recalibrated forward %.2f ms = %.1fx steady (rescale from the maxima, re-capture, the pair "
+          "again); max distance to a fresh model %.2e; back on the first pair %.2e" % (1e3 * t_recal, t_recal / steady, d_far,
+                                                                                      maxabs(back, want0)))
+    assert d_far <= 1e-3 * max(1.0, float(want.abs().max()) / 256.0) and maxabs(back, want0) <= 1e-3
+    # (encoders twice, the loop twice, and the captures of the unit kinds this pair replays; at this small shape a steady forward
+    # is 6 ms and the captures dominate -- at the benchmark shape the same absolute cost is ~2.5 steady forwards)
+    assert t_recal <= 15.0 * steady
 
 
 # ---- bench.py ------------------------------------------------------------------------------------------------------------------

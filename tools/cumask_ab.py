@@ -6,7 +6,7 @@ head -> motion front -> convc2 | convf2 -> encoder.conv) unmasked -- so that the
 waiting for the side chain's resident blocks to retire.  Captured graphs do not carry a stream's CU mask into their kernel
 nodes, so the comparison runs the loop's units as plain launches (RAFTStereo.c8_eager) in every arm, mask or not.
 
-    python tools/cumask_ab.py [N ...]      (default: 0 = no mask, 224 192 160 128; two alternations)
+    python tools/cumask_ab.py [N ...]      (default: 0 = no mask, 224 192 160 128; negative: -N bits of every 32; two alternations)
 Prints ms per iteration of the loop and the in-pipeline duration of the motion front per arm."""
 import ctypes
 import os
@@ -23,10 +23,15 @@ DEV = torch.device("cuda", 0)
 
 
 def masked_stream(n_cus, total=256):
+    """n_cus > 0: the first n_cus mask bits.  n_cus < 0: -n_cus bits of EVERY 32-bit word -- the same number of CUs from every
+    XCD whether the driver lays the mask out XCD-major (bit = 32 * xcd + cu) or deals it round-robin (bit = 8 * cu + xcd)."""
     hip = ctypes.CDLL("libamdhip64.so")
     words = (total + 31) // 32
     mask = (ctypes.c_uint32 * words)()
-    for i in range(n_cus):
+    if n_cus < 0:
+        for w in range(words):
+            mask[w] = (1 << (-n_cus)) - 1
+    for i in range(max(n_cus, 0)):
         mask[i // 32] |= 1 << (i % 32)
     st = ctypes.c_void_p()
     rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
@@ -84,8 +89,9 @@ def main():
                 if rep:
                     ms.append(e0.elapsed_time(e1))
             front_us = 1e3 * sum(a.elapsed_time(b) for a, b in fr) / max(len(fr), 1)
-            print("round %d  side stream on %3s CUs: loop %.3f ms per iteration (%.2f / %.2f / %.2f ms per pair), motion front %.1f us in "
-                  "the pipeline" % (rnd, n or "all", sum(ms) / len(ms) / 32, ms[0], ms[1], ms[2], front_us), flush=True)
+            label = ("%d of every 32" % -n) if n < 0 else (n or "all")
+            print("round %d  side stream on %s CUs: loop %.3f ms per iteration (%.2f / %.2f / %.2f ms per pair), motion front %.1f us in "
+                  "the pipeline" % (rnd, label, sum(ms) / len(ms) / 32, ms[0], ms[1], ms[2], front_us), flush=True)
     upd._SIDE_STREAMS.streams[key] = plain
 
 
