@@ -110,14 +110,14 @@ class TimedCorr:
 
 def pmc_traffic(args):
     """HBM-side bytes per launch of the two reported kernels, measured now: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
-    in SEPARATE sub-runs (kernel trace only) of tools/pmc/pmc_probe_r05.py, which runs this workload's forward with the loop's
+    in SEPARATE sub-runs (kernel trace only) of tools/pmc/pmc_probe.py, which runs this workload's forward with the loop's
     units as plain launches plus a known-traffic calibration stream; reads are FETCH_SIZE x the correction that stream yields."""
     import subprocess
-    script = os.path.join(ROOT, "tools", "pmc", "run_pmc_r05.sh")
+    script = os.path.join(ROOT, "tools", "pmc", "run_pmc.sh")
     try:
         subprocess.run(["bash", script, str(args.batch)], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=2400)
         sfx = "" if args.batch == 1 else "_b%d" % args.batch
-        with open(os.path.join(ROOT, "gpurun_out", "r05_pmc" + sfx, "traffic.json")) as f:
+        with open(os.path.join(ROOT, "gpurun_out", "r06_pmc" + sfx, "traffic.json")) as f:
             j = json.load(f)
         return {"conv_bytes": j.get("gru_bytes"), "lookup_bytes": j.get("motion_front_bytes"),
                 "lookup_operator_bytes": j.get("lookup_operator_bytes"), "note": "measured in this run: %s" % j.get("source")}
@@ -563,10 +563,10 @@ def main():
     # HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     # rocprofv3 runs of the same kernels on the same shapes); None when the file is absent
     # The committed passes are quoted ONLY when they profiled the launch timed here: same image size and batch, fused ConvGRU
-    # launch with the same rider (profiles/r05_hbm_traffic[_b<B>].json record both)
+    # launch with the same rider (profiles/r06_hbm_traffic[_b<B>].json record both)
     traffic = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_hbm_traffic%s.json" % ("" if B == 1 else "_b%d" % B))) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_hbm_traffic%s.json" % ("" if B == 1 else "_b%d" % B))) as f:
             traffic = json.load(f)
     except (OSError, ValueError):
         pass

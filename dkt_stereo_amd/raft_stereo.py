@@ -402,7 +402,8 @@ class RAFTStereo(nn.Module):
                 fmap1, fmap2 = split(self.fnet(fnet_in))
                 self._prebuild(image1, fmap1, fmap2)
             cnet_list = self.cnet(image1, num_layers=n, head_post=self._context_post, begun=begun)
-            if self._defer_join and self._prebuilt is not None and self.defer_fnet_join:
+            if (self._defer_join and self._prebuilt is not None and self.defer_fnet_join
+                    and not torch.cuda.is_current_stream_capturing()):          # (a capture must end with its streams joined)
                 # forward(): the feature maps' only consumer -- the correlation build -- has already been enqueued on the
                 # feature encoder's stream; the loop's prologue forks ITS correlation-dependent half (lookup + motion encoder of
                 # iteration 0) onto that same stream and joins it itself, so the hidden-state half of the prologue (pack, gru32,

@@ -61,7 +61,10 @@ def run(lib, pair=True, reps=300, B=1):
     small = chk.State(*chk.make(B, 46, 78, [128], 2))          # the loop's rider: gru32 at 1/16 resolution
     rounds = 12
     err = torch.zeros(16 + 2 * 8 * 256 * rounds, device="cuda", dtype=torch.int32)
-    d0, d1 = big.desc(), small.desc()
+    passes = int(([a.split("=")[1] for a in sys.argv[1:] if a.startswith("--passes=")] or ["3"])[0])
+    with c8.passes(passes):              # MFMA products per block of the traced launch (1 = what args.mixed_precision runs)
+        d0, d1 = big.desc(), small.desc()
+    print("passes %d" % passes)
     reps = max(3, reps // B)
     for _ in range(reps):
         err[16:].zero_()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""traffic.json (and, with --profiles, profiles/r05_hbm_traffic[_b<B>].{txt,json}) from a tools/pmc/run_pmc_r05.sh output
+"""traffic.json (and, with --profiles, profiles/r06_hbm_traffic[_b<B>].{txt,json}) from a tools/pmc/run_pmc.sh output
 directory: bytes per launch = FETCH_SIZE / (calibrated fraction of the bytes read) + WRITE_SIZE / (calibrated fraction written),
 averaged over the loop's own dispatches (the last 32 fused ConvGRU steps, the last 31 motion fronts of the probe process)."""
 import json
@@ -33,7 +33,7 @@ comp = px * 6656 + px32 * 5632 + 8.8e6
 alg_front = px * 764
 alg_op = px * 308
 j = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch of the loop's own launches (tools/pmc/run_pmc_r05.sh); "
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per dispatch of the loop's own launches (tools/pmc/run_pmc.sh); "
               "reads = FETCH_SIZE / %.3f, writes = WRITE_SIZE / %.3f from 1 GiB known-traffic streams in the same passes" % (ff, wf),
     "shape": [736, 1248, B], "gru_rider_hw": [46, 78],
     "fetch_fraction": ff, "write_fraction": wf,
@@ -42,7 +42,7 @@ j = {
     "lookup_operator_bytes": int(o_f + o_w), "lookup_operator_algorithmic_bytes": int(alg_op),
 }
 json.dump(j, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-txt = """# HBM-side traffic of the kernels bench.py reports (MI355X, round 5, batch %d): bash tools/pmc/run_pmc_r05.sh %d
+txt = """# HBM-side traffic of the kernels bench.py reports (MI355X, round 6, batch %d): bash tools/pmc/run_pmc.sh %d
 #   fused ConvGRU launch (gru_c8_kernel, gru08 184x312 + gru32 46x78 -- the loop's own dispatches): %.1f MB read + %.1f MB written
 #       = %.1f MB per launch vs %.1f MB compulsory = %.2fx
 #   motion front (coordinate update + lookup + convc1 + 7x7 stem -> C8S): %.1f MB vs %.1f MB algorithmic = %.2fx
@@ -53,6 +53,6 @@ print(txt)
 if "--profiles" in sys.argv:
     sfx = "" if B == 1 else "_b%d" % B
     body = open(os.path.join(out, "summary_tail.txt")).read()
-    open(os.path.join(ROOT, "profiles", "r05_hbm_traffic%s.txt" % sfx), "w").write(txt + body)
-    j["source"] = "profiles/r05_hbm_traffic%s.txt (%s)" % (sfx, j["source"])
-    json.dump(j, open(os.path.join(ROOT, "profiles", "r05_hbm_traffic%s.json" % sfx), "w"), indent=1)
+    open(os.path.join(ROOT, "profiles", "r06_hbm_traffic%s.txt" % sfx), "w").write(txt + body)
+    j["source"] = "profiles/r06_hbm_traffic%s.txt (%s)" % (sfx, j["source"])
+    json.dump(j, open(os.path.join(ROOT, "profiles", "r06_hbm_traffic%s.json" % sfx), "w"), indent=1)

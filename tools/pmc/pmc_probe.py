@@ -4,7 +4,7 @@ probe launched the fused ConvGRU step with a 23x39 rider where the loop's is 46x
 benchmark model with its units as plain launches (model.c8_eager), after the forwards that calibrate and capture -- the LAST 32
 gru_c8_kernel and 31 motion_front_kernel dispatches of the process are the loop's own -- plus the reference-visible lookup
 operator and the known-traffic calibration kernels; wrapped by rocprofv3 --pmc FETCH_SIZE (one run) and --pmc WRITE_SIZE
-(another): tools/pmc/run_pmc_r05.sh [batch]."""
+(another): tools/pmc/run_pmc.sh [batch]."""
 import ctypes
 import os
 import sys
