@@ -262,5 +262,12 @@ def cfg5():
 
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg3", "cfg4", "cfg5"]
-    for w in which:
-        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[w]()
+    flags = [a for a in sys.argv[1:] if a.startswith("--")]
+    if len(which) > 1:
+        # one process per configuration: the CPU baselines leave 100+ OpenMP threads behind, and the next configuration's
+        # launches would be timed beside them (round 6: cfg4 measured 562 ms per batch behind cfg3's CPU sample, 236 alone)
+        import subprocess
+        for w in which:
+            subprocess.run([sys.executable, os.path.abspath(__file__), w] + flags, check=False)
+    else:
+        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[which[0]]()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the device idles inside one stereo pair: from a rocprofv3 kernel trace, the window between two consecutive
-corr1d_build dispatches; every interval of at least --min microseconds in which NO queue runs a kernel, with the kernels on
+normalize_pair dispatches (a forward's first launch); every interval of at least --min microseconds in which NO queue runs a kernel, with the kernels on
 either side.  Used to compare the product's default mode (check_finite = True: one host synchronisation per pair) with the
 unchecked mode bench.py's timed region runs.   idle_gaps.py <kernel_trace.csv> [--pair -3] [--min 10]"""
 import argparse
@@ -20,7 +20,7 @@ def main():
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "normalize_pair" in r["Kernel_Name"]]
     lo, hi = idx[a.pair], idx[a.pair + 1]
     win = rows[lo:hi]
     t0 = int(win[0]["Start_Timestamp"])

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel breakdown of ONE steady-state stereo pair from a rocprofv3 kernel trace of
-bench.py: the window between two consecutive corr1d_build dispatches of the timed region
+bench.py: the window between two consecutive normalize_pair dispatches (a forward's first launch) of the timed region
 (bench.py's warm-up contains MIOpen's find-mode benchmarking, which would otherwise swamp
-the table).  Usage: rocprof_pair_breakdown.py <kernel_trace.csv> [--pair -3]"""
+the table).  Usage: rocprof_pair_breakdown.py <kernel_trace.csv> [--pair 6] [--phases --encoders --timeline 10]"""
 import argparse
 import collections
 import csv
@@ -12,7 +12,7 @@ import re
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
-    ap.add_argument("--pair", type=int, default=-3, help="index of the corr1d_build dispatch that opens the window")
+    ap.add_argument("--pair", type=int, default=-3, help="index of the forward (normalize_pair dispatch) that opens the window")
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--timeline", type=int, default=None, metavar="IT",
                     help="also list every dispatch of GRU iteration IT of the pair (start offset, duration, grid)")
@@ -23,43 +23,41 @@ def main():
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
+    # A pair = from its input normalisation (normalize_pair_kernel, the forward's first launch) to the next pair's.  Since round 6
+    # the loop's prologue starts beside the feature encoder's tail (the correlation build is no longer a clean boundary), so the
+    # pair is cut into "encoders" and "loop" at the loop's own first launch: the pack of the hidden states (act_c8_pack_kernel).
+    idx = [i for i, r in enumerate(rows) if "normalize_pair" in r["Kernel_Name"]]
     lo, hi = idx[a.pair], idx[a.pair + 1]
     win = rows[lo:hi]
+    cut = next((i for i, r in enumerate(win) if "act_c8_pack" in r["Kernel_Name"]), len(win))
+    enc, loop = win[:cut], win[cut:]
+
+    def show(r, t0):
+        n = re.sub(r"^void ", "", re.sub(r"\(.*", "", r["Kernel_Name"]))[:64]
+        print("%9.1f %9.1f %9.1f  q%-3s %-64s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
+                                         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                         (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"), n,
+                                         r.get("Grid_Size_X", r.get("Grid_Size", ""))))
+
     if a.timeline is not None:
-        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"] or "motion_front" in r["Kernel_Name"]]
-        it = win[lk[a.timeline]:lk[a.timeline + 1]]
+        lk = [i for i, r in enumerate(loop) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"] or "motion_front" in r["Kernel_Name"]]
+        it = loop[lk[a.timeline]:lk[a.timeline + 1]]
         t0 = int(it[0]["Start_Timestamp"])
         print("# dispatches of GRU iteration %d (start offset us, duration us, end offset us, queue, kernel, grid threads); two streams overlap" % a.timeline)
         for r in it:
-            n = re.sub(r"^void ", "", re.sub(r"\(.*", "", r["Kernel_Name"]))[:64]
-            print("%9.1f %9.1f %9.1f  q%-3s %-64s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
-                                             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                                             (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"), n,
-                                             r.get("Grid_Size_X", r.get("Grid_Size", ""))))
+            show(r, t0)
         print("# iteration wall: %.1f us" % ((int(it[-1]["End_Timestamp"]) - t0) / 1e3))
     if a.phases:
-        # Since round 4 the correlation build runs inside the encoder phase (on the feature encoder's stream), so the pair is
-        # cut at the loop's own first launch -- the pack of the hidden states into C8S (act_c8_pack_kernel) -- when there is one.
-        packs = [i for i, r in enumerate(rows) if "act_c8_pack" in r["Kernel_Name"]]
-        start = next((i for i in packs if i >= lo), lo)
-        nxt = next((i for i in packs if i > start + 8), None)
-        if nxt is None or not packs:
-            start, nxt = lo, hi
-        win = rows[start:nxt]
-        lk = [i for i, r in enumerate(win) if "lookup" in r["Kernel_Name"] or "corr_feat" in r["Kernel_Name"] or "motion_front" in r["Kernel_Name"]]
-        end = lk[-1] + (lk[-1] - lk[-2])          # the last iteration is as long as the one before it
-        table(win[:end], a.top, "GRU loop (prologue + %d iterations)" % (len(lk) + 1))
-        table(win[end:], a.top, "upsampling + encoders + correlation build of the next pair")
+        print("# pair wall (normalisation to the next pair's normalisation): %.2f ms"
+              % ((int(rows[hi]["Start_Timestamp"]) - int(win[0]["Start_Timestamp"])) / 1e6))
+        table(loop, a.top, "GRU loop (from the first pack of the hidden states: prologue + 32 iterations + mask head + up-sampling; the "
+                           "feature encoder's tail and the correlation build run beside its prologue)")
+        table(enc, a.top, "input normalisation + encoders up to the loop's first launch")
         if a.encoders:
-            t0 = int(win[end]["Start_Timestamp"])
-            print("# dispatches of the up-sampling + encoder phase (start offset us, duration us, end offset us, queue, kernel, grid)")
-            for r in win[end:]:
-                n = re.sub(r"^void ", "", re.sub(r"\(.*", "", r["Kernel_Name"]))[:64]
-                print("%9.1f %9.1f %9.1f  q%-3s %-64s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
-                                                 (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                                                 (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"), n,
-                                                 r.get("Grid_Size_X", r.get("Grid_Size", ""))))
+            t0 = int(win[0]["Start_Timestamp"])
+            print("# dispatches from the pair's first launch to 12 launches past the loop's first (start offset us, duration us, end offset us, queue, kernel, grid)")
+            for r in win[:cut + 12]:
+                show(r, t0)
     else:
         table(win, a.top, "one steady-state pair")
 
