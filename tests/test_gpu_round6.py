@@ -139,6 +139,28 @@ def test_iterate_verifies_for_direct_callers():
     assert lp.status().err == 1
 
 
+@torch.no_grad()
+def test_fused_gru_one_product_with_an_odd_chunk_count_takes_two():
+    """The one-product kernel walks the x chunks in pairs: a ConvGRU whose x operands give an odd number of 16-channel chunks gets
+    the two-product form from gru_desc (as conv_c8.desc does for its layers) instead of a declined launch -- which used to switch
+    the fused ConvGRU off for every later unit of the loop."""
+    from test_gpu_round4 import _State, _make
+    from dkt_stereo_amd import conv_c8 as c8
+    gru, h, xs, cz, cr, cq = _make(1, 64, 96, [128, 16], seed=11)         # 8 + 1 chunks of x
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    a, b = _State(gru, h, xs, cz, cr, cq), _State(gru, h, xs, cz, cr, cq)
+    with c8.passes(1):
+        d1 = a.desc()
+    with c8.passes(2):
+        d2 = b.desc()
+    assert d1.passes == 2 and d2.passes == 2
+    assert c8.gru_launch(d1, err=err) and c8.gru_launch(d2, err=err)
+    assert torch.equal(a.h, b.h) and int(err.item()) == 0
+    gru2, h2, xs2, cz2, cr2, cq2 = _make(1, 64, 96, [128, 128], seed=12)    # an even count keeps the one-product form
+    with c8.passes(1):
+        assert _State(gru2, h2, xs2, cz2, cr2, cq2).desc().passes == 1
+
+
 # ---- args.mixed_precision ------------------------------------------------------------------------------------------------------
 @torch.no_grad()
 def test_mixed_precision_flag(golden):
