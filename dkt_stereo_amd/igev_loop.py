@@ -347,7 +347,29 @@ def _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, i
     ub = update_block
     if USE_C8 and loop_c8.eligible_igev(ub, st.net[0].shape):
         out = _iterate_c8(ub, st, iters)
-        word = st.c8.take_error_word()
+        # the post-conditions of this call in one launch and one host read (csrc/status.hip, as RAFTStereo.iterate): the error
+        # word of the flag-synchronised launches, finiteness of the disparity, the C8S scale window
+        status = st.c8.status(out[0])
+        word = status.err
+        if not word and st.c8.calibrated and not (status.finite and status.ranges_ok) and getattr(st, "rescaled", 0) < 2:
+            # this pair's activations left the window the scales were picked for (round 6: IGEV's loop never looked): new scales
+            # -- from the maxima the call left behind when they are finite, a trial run otherwise -- and the call again
+            import math
+            st.rescaled = getattr(st, "rescaled", 0) + 1
+            st.c8.recalibrations += 1
+            if status.finite and all(math.isfinite(v) for v in status.maxima.reshape(-1).tolist()):
+                st.c8.rescale_from(status.maxima)
+                st.c8.calibrations += 1
+            else:
+                st.c8.calibrated = False
+            try:
+                return _igev_iterate(update_block, geo_fn, init_disp, coords, net_list, inp_list, iters, use_hip_graph,
+                                     cache if cache is not None else dict(state=st))
+            finally:
+                st.rescaled = 0
+        if not word and not status.finite:
+            raise _conv._ffi.DktError("igev_iterate produced a non-finite disparity: an activation left the range of the "
+                                      "split-fp16 convolutions (or the inputs were not finite)")
         if word:
             # a fused ConvGRU (bit 0) or chain (bit 1) launch gave up waiting for a neighbour tile (csrc/gru_c8.hip; ADVICE
             # r04): the result is wrong.  That form is left for good, and this call is computed again from the caller's

@@ -272,6 +272,54 @@ def test_igev_data_parallel_replicas_run_on_a_persistent_shadow():
     assert maxabs(o[0], want2[0]) <= 1e-3
 
 
+@torch.no_grad()
+def test_igev_loop_rescales_when_the_disparity_leaves_the_window():
+    """igev_iterate checks its call's post-conditions like RAFTStereo.iterate (round 6): an initial disparity 2^8 above the one the
+    scales were picked on is rescaled from the maxima the call left behind and repeated -- the result equals a fresh state's."""
+    from test_gpu_round2 import _igev_setup
+    from dkt_stereo_amd import igev_loop
+    c = _cases.IGEV_LOOP_CASES["kitti"]
+    blk, geo_fn, d0, coords, net, inp, _ = _igev_setup(c)
+    cache = {}
+    run = lambda d, ca: igev_loop.igev_iterate(blk, geo_fn, d, coords, [t.clone() for t in net], inp, 6, cache=ca)
+    run(d0, cache)
+    lp = cache["state"].c8
+    r0 = lp.recalibrations
+    far = d0 * 600.0
+    got = run(far, cache)
+    assert lp.recalibrations == r0 + 1 and cache["state"].c8 is lp
+    want = run(far, {})
+    scale = max(1.0, float(want[0].abs().max()) / 256.0)
+    assert maxabs(got[0], want[0]) <= 1e-3 * scale and maxabs(got[1], want[1]) <= 1e-3 * scale
+    again = run(far, cache)
+    assert lp.recalibrations == r0 + 1 and torch.equal(again[0], got[0])
+
+
+@torch.no_grad()
+def test_deferred_encoder_join_and_lazy_capture_change_nothing():
+    """forward() leaves the join of the feature encoder's stream to the loop's prologue and captures each kind of unit on first
+    use (round 6); encode() + iterate() called directly join in encode().  Same bits either way, and as a loop whose every kind of
+    unit was captured up front."""
+    i1, i2 = (G(t) for t in _synth.image_pair(8, 1, 544, 960, 40))
+    a, _ = _raft()
+    b, _ = _raft()
+    b.defer_fnet_join = False
+    for k in range(3):
+        _, ua = a(i1, i2, iters=11, test_mode=True)
+        _, ub = b(i1, i2, iters=11, test_mode=True)
+        assert torch.equal(ua, ub), k
+    _, uc = a.iterate(*a.encode(i1, i2), 11)
+    assert torch.equal(uc, ua)
+    lp = a._graph_state["c8"]
+    kinds = {("one",) + k for k in lp.graph} | {("n",) + k for k in lp.graph_n} | {("last",) + k for k in lp.graph_last}
+    assert 3 <= len(kinds) < 6, kinds                          # not every (kind, parity) is needed by an 11-iteration pair
+    from dkt_stereo_amd.update import capture_graph
+    lp.capture(a._graph_state, capture_graph, 3)
+    assert len(lp.graph) + len(lp.graph_n) + len(lp.graph_last) == 6
+    _, ud = a(i1, i2, iters=11, test_mode=True)
+    assert torch.equal(ud, ua)
+
+
 # ---- calibration stress (VERDICT r05 item 8) -----------------------------------------------------------------------------------
 @torch.no_grad()
 def test_calibration_stress_twenty_pairs():
