@@ -209,6 +209,28 @@ def test_mixed_precision_encoders_run_one_product():
     assert 1e-5 < rel < 5e-2, rel                            # fp16-rounded operands: visible, and small
 
 
+@torch.no_grad()
+def test_mixed_precision_on_the_loops_the_c8_path_does_not_take():
+    """slow_fast_gru / two GRU levels stay on the round-2 loop: with mixed_precision it runs on the one-product backend (`f16`), the
+    key off it is the reference fixture's parity path, and the process-wide backend is untouched either way."""
+    from dkt_stereo_amd import conv
+    c = _cases.E2E_SLOWFAST_CASES["sf2_64x128_it6"]
+    i1, i2 = (G(t) for t in _synth.image_pair(c["seed"], c["B"], c["H"], c["W"], c["shift"]))
+    over = dict(slow_fast_gru=True, n_gru_layers=c["n"])
+    off, _ = _raft(**over)
+    on, _ = _raft(mixed_precision=True, **over)
+    _, want = off(i1, i2, iters=c["iters"], test_mode=True)
+    _, got = on(i1, i2, iters=c["iters"], test_mode=True)
+    assert conv.get_backend() == "f16x3"
+    st = on._graph_state
+    assert st is None or st.get("c8") is None                 # (not the C8S loop)
+    d = maxabs(got, want)
+    print("mixed_precision on the round-2 loop: max|d| %.3e from the fp32-class path" % d)
+    assert 1e-6 < d <= 1e-1
+    _, again = on(i1, i2, iters=c["iters"], test_mode=True)
+    assert torch.equal(again, got)
+
+
 # ---- IGEV under nn.DataParallel replicas -----------------------------------------------------------------------------------------
 @torch.no_grad()
 def test_igev_data_parallel_replicas_run_on_a_persistent_shadow():
