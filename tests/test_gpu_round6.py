@@ -10,7 +10,6 @@
   default mode;
 * bench.py's default-mode value, error word and --distinct-pairs on a small shape.
 """
-import ctypes
 import json
 import os
 import subprocess
